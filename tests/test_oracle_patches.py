@@ -1,0 +1,135 @@
+"""Pin oracle/patches_oracle.py against outputs of the reference's own utils/patches.py
+(tests/golden/*.npz, produced by tests/golden/make_golden_patches.py)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle import patches_oracle as po
+
+CASES20 = ['patches_20_div.npz', 'patches_20_nondiv.npz', 'patches_20_b8.npz']
+CASES60 = ['patches_60_div.npz', 'patches_60_nondiv.npz', 'patches_60_b12.npz']
+
+# skimage 0.18.3 interpolates with float32 sample coordinates.  Two checks:
+#  * oracle in f32-coordinate mode vs reference: a few float32 ulp (values <= 13110 -> ulp <= 9.8e-4);
+#  * oracle in exact-coordinate mode vs reference: coordinate error <= ~2e-6 of a pixel times the local
+#    gradient (<= 13110 / pixel) -> 0.03 raw reflectance units = 1.5e-5 after /2000 (gate: 1e-4 RMSE).
+TIGHT = dict(rtol=4e-7, atol=2e-3)
+LOOSE = dict(rtol=0, atol=3e-2)
+
+
+def check_interp(fn, expect, err_msg=''):
+    np.testing.assert_allclose(fn(True), expect, err_msg=err_msg + ' (f32 coords)', **TIGHT)
+    np.testing.assert_allclose(fn(False), expect, err_msg=err_msg + ' (exact coords)', **LOOSE)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+@pytest.mark.parametrize('name', CASES20)
+def test_get_test_patches_matches_reference(golden_dir, name):
+    g = load(golden_dir, name)
+    d10, d20 = g['d10'].astype(np.float32), g['d20'].astype(np.float32)
+    patch, border = int(g['patch']), int(g['border'])
+    p10, p20 = po.get_test_patches(d10, d20, patchSize=patch, border=border)
+    assert p10.dtype == np.float32 and p20.dtype == np.float32
+    assert np.array_equal(p10, g['p10'])                       # tiling is a pure copy: bit-exact
+    _, raw = po.get_test_patches(d10, d20, patchSize=patch, border=border, interp=False)
+    assert np.array_equal(raw, g['p20_raw'])
+    check_interp(lambda f: po.get_test_patches(d10, d20, patchSize=patch, border=border, f32_coords=f)[1], g['p20'])
+
+
+@pytest.mark.parametrize('name', CASES60)
+def test_get_test_patches60_matches_reference(golden_dir, name):
+    g = load(golden_dir, name)
+    d = [g[k].astype(np.float32) for k in ('d10', 'd20', 'd60')]
+    patch, border = int(g['patch']), int(g['border'])
+    p10, p20, p60 = po.get_test_patches60(*d, patchSize=patch, border=border)
+    assert np.array_equal(p10, g['p10'])
+    _, r20, r60 = po.get_test_patches60(*d, patchSize=patch, border=border, interp=False)
+    assert np.array_equal(r20, g['p20_raw']) and np.array_equal(r60, g['p60_raw'])
+    check_interp(lambda f: po.get_test_patches60(*d, patchSize=patch, border=border, f32_coords=f)[1], g['p20'])
+    check_interp(lambda f: po.get_test_patches60(*d, patchSize=patch, border=border, f32_coords=f)[2], g['p60'])
+
+
+@pytest.mark.parametrize('name', CASES20 + CASES60)
+def test_recompose_matches_reference(golden_dir, name):
+    g = load(golden_dir, name)
+    rec = quiet(po.recompose_images, g['pred'], border=int(g['border']), size=g['d10'].shape)
+    assert rec.dtype == np.float32 and rec.shape == g['rec'].shape
+    assert np.array_equal(rec, g['rec'])
+
+
+@pytest.mark.parametrize('name', CASES20)
+def test_recompose_of_tiling_is_identity(golden_dir, name):
+    """recompose(get_test_patches(d10,...)[0]) == d10 exactly."""
+    g = load(golden_dir, name)
+    d10 = g['d10'].astype(np.float32)
+    p10, _ = po.get_test_patches(d10, g['d20'].astype(np.float32), patchSize=int(g['patch']), border=int(g['border']))
+    rec = quiet(po.recompose_images, p10, border=int(g['border']), size=d10.shape)
+    assert np.array_equal(rec, d10)
+    assert np.array_equal(rec, g['rec_identity'])
+
+
+def test_trailing_patches_are_zero_when_stride_divides(golden_dir):
+    """patches.py:35 allocates (k+1)^2 patches; with a dividing stride the trailing ones stay zero."""
+    g = load(golden_dir, 'patches_20_div.npz')
+    p10, p20 = po.get_test_patches(g['d10'].astype(np.float32), g['d20'].astype(np.float32),
+                                   patchSize=int(g['patch']), border=int(g['border']))
+    assert p10.shape[0] == 16 and not p10[9:].any() and not p20[9:].any()
+    assert p10[:9].all()
+
+
+def test_single_patch_is_returned_uncropped(golden_dir):
+    g = load(golden_dir, 'recompose_single.npz')
+    rec = po.recompose_images(g['pred'], border=4, size=(24, 24, 4))
+    assert rec.shape == (32, 32, 6) and np.array_equal(rec, g['rec'])
+
+
+def test_interp_patches_matches_reference(golden_dir):
+    g = load(golden_dir, 'interp.npz')
+    for src, key, shape in [('ramp', 'ramp_x2', (1, 1, 8, 8)), ('ramp', 'ramp_x6', (1, 1, 24, 24)),
+                            ('a', 'a_x2', (3, 2, 32, 32)), ('a', 'a_x6', (3, 2, 96, 96)),
+                            ('b', 'b_x2', (2, 3, 10, 14)), ('b', 'b_x6', (2, 3, 30, 42))]:
+        out = po.interp_patches(g[src], shape)
+        assert out.dtype == np.float32 and out.shape == g[key].shape
+        check_interp(lambda f: po.interp_patches(g[src], shape, f32_coords=f), g[key], key)
+
+
+def test_mirror_bilinear_ramp_known_answer():
+    """ramp 0 10 20 30, x2 -> 2.5 2.5 7.5 ... 27.5 27.5 (mirror, not clamp)."""
+    ramp = np.array([[0, 10, 20, 30]], np.float32).repeat(4, axis=0)[None, None]
+    x2 = po.interp_patches(ramp, (1, 1, 8, 8))[0, 0, 0]
+    np.testing.assert_allclose(x2, [2.5, 2.5, 7.5, 12.5, 17.5, 22.5, 27.5, 27.5], rtol=1e-6)
+    x6 = po.interp_patches(ramp, (1, 1, 24, 24))[0, 0, 0]
+    np.testing.assert_allclose(x6[:5], [25 / 6, 2.5, 5 / 6, 5 / 6, 2.5], rtol=1e-5)
+
+
+def test_real_tile_crop_default_geometry(golden_dir):
+    """Default geometry of testing/supres.py (128/8 and 192/12) on a crop of the bundled T33UUB tile."""
+    g = load(golden_dir, 'tile_T33UUB_crop.npz')
+    d = [g[k].astype(np.float32) for k in ('d10', 'd20', 'd60')]
+    p10, p20 = po.get_test_patches(d[0], d[1], patchSize=128, border=8, f32_coords=True)
+    assert p10.shape[0] == int(g['n20']) == 9
+    np.testing.assert_array_equal(p10.astype(np.float64).sum(axis=(2, 3)), g['p10_sum'])
+    sub = (slice(None), slice(None), slice(3, None, 7), slice(2, None, 5))
+    np.testing.assert_allclose(p20[sub], g['p20_sub'], **TIGHT)
+    np.testing.assert_allclose(p20[4, :2], g['p20_patch4'], **TIGHT)
+    np.testing.assert_allclose(p20.astype(np.float64).sum(axis=(2, 3)), g['p20_sum'], rtol=1e-6)
+    q10, q20, q60 = po.get_test_patches60(*d, patchSize=192, border=12, f32_coords=True)
+    assert q10.shape[0] == int(g['n60']) == 4
+    np.testing.assert_array_equal(q10.astype(np.float64).sum(axis=(2, 3)), g['q10_sum'])
+    np.testing.assert_allclose(q20[sub], g['q20_sub'], **TIGHT)
+    np.testing.assert_allclose(q60[sub], g['q60_sub'], **TIGHT)
+    np.testing.assert_allclose(q60[0, :1], g['q60_patch0'], **TIGHT)
+    # round trip on the real data
+    rec = quiet(po.recompose_images, p10, border=8, size=d[0].shape)
+    assert np.array_equal(rec, d[0])
