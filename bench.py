@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: 32x32 patches/s for DSen2_20 (d=6, F=128, fp32) at
+batch 512 per GPU, synthetic inputs resident in HBM, random-init (he_uniform) weights.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N>1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+one rank per GPU over RCCL.  A step = one forward pass of 512 patches per rank (weak scaling: patches
+are independent units, no collective inside the network); the all-gather of the step's outputs
+("gather of outputs over xGMI") is issued asynchronously after each step and completed inside the
+timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 512
+H = W = 32
+BANDS = (4, 6)
+NUM_LAYERS, FEAT = 6, 128
+FLOP_PER_PIXEL_BODY = 2 * 9 * FEAT * FEAT                       # one 3x3x128x128 conv: 294 912 FLOP / px
+FLOP_PER_PIXEL_NET = 2 * 9 * (sum(BANDS) * FEAT + 2 * NUM_LAYERS * FEAT * FEAT + FEAT * BANDS[-1])
+PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md: Peak FP32 (matrix)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=BATCH, help=argparse.SUPPRESS)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU work for cpu_baseline')
+    ap.add_argument('--no-gather', action='store_true', help='skip the per-step output all-gather (N>1)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as td
+    from dsen2_amd import dist as ddist
+    from dsen2_amd import weights as dweights
+    from dsen2_amd.DSen2Net import s2model
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; launch N>1 with torch.distributed.run\n'
+                             % (args.gpus, world))
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        td.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    # ---- setup (untimed): weights on rank 0 -> RCCL broadcast; synthetic inputs in HBM ----
+    n_params = dweights.num_params(sum(BANDS), BANDS[-1], NUM_LAYERS, FEAT)
+    flat = dweights.random_he_uniform(sum(BANDS), BANDS[-1], NUM_LAYERS, FEAT, seed=1) if rank == 0 else None
+    flat = ddist.broadcast_weights(flat, n_params, device=dev)
+    model = s2model(tuple((b, None, None) for b in BANDS), num_layers=NUM_LAYERS, feature_size=FEAT, device=dev)
+    model.set_weights_flat(flat)
+    rng = np.random.Generator(np.random.PCG64(rank))             # U[0,1)*5, PCG64(seed)
+    xs_np = [(rng.random((args.batch, c, H, W), dtype=np.float32) * np.float32(5.0)) for c in BANDS]
+    xs = [torch.from_numpy(a).to(dev) for a in xs_np]
+    out = torch.empty((args.batch, BANDS[-1], H, W), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * args.batch, BANDS[-1], H, W), dtype=torch.float32, device=dev) if world > 1 else None
+    do_gather = world > 1 and not args.no_gather
+
+    def step():
+        model.forward_device(xs, out=out)
+        if do_gather:
+            return td.all_gather_into_tensor(gathered, out, async_op=True)
+        return None
+
+    for _ in range(args.warmup):
+        h = step()
+        if h is not None:
+            h.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pending = None
+    for _ in range(args.steps):
+        if pending is not None:
+            pending.wait()                                       # previous step's gather must have read `out`
+        pending = step()
+    if pending is not None:
+        pending.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        td.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+
+    result = {
+        'metric': '32x32x6 patches/sec (DSen2_20, d=6, batch 512)',
+        'value': round(value, 1), 'unit': 'patches/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'DSen2_20 d=6 F=128 fp32, %d synthetic 32x32 patches (4+6 bands) per GPU per step, '
+                               'he_uniform random-init weights' % args.batch,
+                   'batch_per_gpu': args.batch, 'patch': [H, W], 'parallelism': 'patch-sharded dp%d' % world,
+                   'output_gather': bool(do_gather)},
+        'net_tflops': round(value * H * W * FLOP_PER_PIXEL_NET / 1e12, 2),
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the 3x3x128x128 body convolution (98.97 % of FLOPs) ----
+        pix = args.batch * H * W
+        a = torch.randn((args.batch, H, W, FEAT), dtype=torch.float32, device=dev)
+        r = torch.randn((args.batch, H, W, FEAT), dtype=torch.float32, device=dev)
+        o = torch.empty_like(a)
+        ms_relu = model.time_body_conv(1, a, None, o, iters=10)          # conv-A (+bias+ReLU)
+        ms_res = model.time_body_conv(2, a, r, o, iters=10)              # conv-B (+bias, *0.1, +residual)
+        ms = 0.5 * (ms_relu + ms_res)
+        flops = pix * FLOP_PER_PIXEL_BODY
+        achieved = flops / (ms * 1e-3) / 1e12
+        result['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                              'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                              'kernel': 'conv3x3_mfma_kernel<128,32,128,128> (body 3x3x128x128, fp32 MFMA 32x32x2)',
+                              'ms_per_launch': round(ms, 4), 'ms_relu': round(ms_relu, 4), 'ms_residual': round(ms_res, 4),
+                              'flop_per_launch': flops}
+        del a, r, o
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the same graph on the host cores, bounded sample (oracle/ = checker code) ----
+        from oracle import cpu_graph
+        pps, sample, cores, y_cpu = cpu_graph.time_patches_per_s(flat, xs_np, NUM_LAYERS, FEAT, budget_s=args.cpu_budget)
+        result['cpu_baseline'] = {'value': round(pps, 2), 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
+                                  'sample': '%d patches of the same synthetic batch, torch-CPU fp32 conv2d graph '
+                                            '(oneDNN), ~%.0f s' % (sample, args.cpu_budget)}
+        n = y_cpu.shape[0]
+        diff = out[:n].cpu().numpy().astype(np.float64) - y_cpu.astype(np.float64)
+        result['rmse_vs_cpu_fp32'] = float(np.sqrt(np.mean(diff * diff)))
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

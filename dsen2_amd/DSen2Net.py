@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's network module (utils/DSen2Net.py) over libdsen2_hip.so.
+
+``s2model(input_shape, num_layers, feature_size)`` keeps the reference's name, arguments and defaults
+(utils/DSen2Net.py:18) and returns an object with the two keras.Model methods the inference path uses:
+``load_weights(path)`` (testing/supres.py:63) and ``predict(list_of_arrays, verbose=...)`` (supres.py:65).
+All arithmetic happens in the HIP kernels behind the C ABI; PyTorch-ROCm only provides device buffers,
+H2D/D2H copies and the stream.
+"""
+import ctypes
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib, weights as _weights
+
+RES_SCALE = 0.1   # resBlock(scale=0.1), utils/DSen2Net.py:9
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class S2Model(object):
+    """What keras' Model is to the reference: built by s2model(), then load_weights() and predict()."""
+
+    def __init__(self, input_shape, num_layers, feature_size, device=None):
+        if len(input_shape) not in (2, 3):
+            raise ValueError('input_shape must describe 2 or 3 inputs, got %r' % (input_shape,))
+        if not torch.cuda.is_available():
+            raise RuntimeError('dsen2_amd needs a ROCm GPU (gfx950); there is no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.bands = tuple(int(s[0]) for s in input_shape)
+        self.num_layers = int(num_layers)
+        self.feature_size = int(feature_size)
+        self.cin = sum(self.bands)
+        self.cout = self.bands[-1]          # utils/DSen2Net.py:35 — input_shape[-1][0]
+        self._handle = ctypes.c_void_p(0)
+        c60 = self.bands[2] if len(self.bands) == 3 else 0
+        with torch.cuda.device(self.device):
+            _lib.call('dsen2_model_create', ctypes.byref(self._handle), self.bands[0], self.bands[1], c60,
+                      self.num_layers, self.feature_size, 0)
+        self._workspace = None
+        self.max_workspace_bytes = 6 << 30   # predict() sizes its internal batches to stay below this
+
+    # -- keras.Model surface -------------------------------------------------------------------
+    def count_params(self):
+        return int(_lib.load().dsen2_model_num_params(self._handle))
+
+    def set_weights_flat(self, flat):
+        flat = np.ascontiguousarray(flat, np.float32).ravel()
+        with torch.cuda.device(self.device):
+            _lib.call('dsen2_model_load_weights', self._handle,
+                      flat.ctypes.data_as(_lib.c_float_p), flat.size)
+
+    def load_weights(self, path):
+        self.set_weights_flat(_weights.load_flat(path, self.cin, self.cout, self.num_layers, self.feature_size))
+
+    def workspace_bytes(self, n, h, w):
+        out = ctypes.c_size_t(0)
+        _lib.call('dsen2_model_workspace_bytes', self._handle, n, h, w, ctypes.byref(out))
+        return out.value
+
+    def _get_workspace(self, nbytes):
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = None
+            self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def forward_device(self, xs, out=None):
+        """One batch entirely on the device: xs = list of contiguous float32 CUDA tensors [n,c,h,w]."""
+        if len(xs) != len(self.bands):
+            raise ValueError('expected %d inputs, got %d' % (len(self.bands), len(xs)))
+        n, _, h, w = xs[0].shape
+        for x, c in zip(xs, self.bands):
+            if tuple(x.shape) != (n, c, h, w) or x.dtype != torch.float32 or not x.is_contiguous() or \
+                    x.device != self.device:
+                raise ValueError('input must be a contiguous float32 %s tensor of shape %r, got %r %s %s'
+                                 % (self.device, (n, c, h, w), tuple(x.shape), x.dtype, x.device))
+        if out is None:
+            out = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=self.device)
+        ws = self._get_workspace(self.workspace_bytes(n, h, w))
+        with torch.cuda.device(self.device):
+            _lib.call('dsen2_model_forward', self._handle, _ptr(xs[0]), _ptr(xs[1]),
+                      _ptr(xs[2]) if len(xs) == 3 else ctypes.c_void_p(0), _ptr(out), n, h, w,
+                      _ptr(ws), ws.numel(), _stream_ptr(self.device))
+        return out
+
+    def batch_limit(self, h, w):
+        per = self.workspace_bytes(1, h, w)
+        return max(1, int(self.max_workspace_bytes // per))
+
+    def predict(self, x, batch_size=None, verbose=0):
+        """keras Model.predict: list of NCHW float32 ndarrays -> ndarray [N, cout, H, W].
+
+        ``batch_size`` only bounds device memory (results do not depend on it); default: as many
+        patches as fit ``max_workspace_bytes``.
+        """
+        xs = [np.ascontiguousarray(a, dtype=np.float32) for a in x]
+        n, _, h, w = xs[0].shape
+        bs = self.batch_limit(h, w) if batch_size is None else int(batch_size)
+        out = np.empty((n, self.cout, h, w), np.float32)
+        for i0 in range(0, n, bs):
+            i1 = min(n, i0 + bs)
+            dev = [torch.from_numpy(a[i0:i1]).to(self.device, non_blocking=False) for a in xs]
+            y = self.forward_device(dev)
+            out[i0:i1] = y.cpu().numpy()
+            if verbose:
+                sys.stdout.write('\r%d/%d' % (i1, n))
+                sys.stdout.flush()
+        if verbose:
+            sys.stdout.write('\n')
+        return out
+
+    def time_body_conv(self, layer, x_in, aux, out, iters=10):
+        """Mean duration (ms) of `iters` launches of body convolution `layer` (1-based), HIP events on the
+        launch stream — bench.py's roofline measurement."""
+        n, h, w, _ = x_in.shape
+        ms = ctypes.c_float(0)
+        with torch.cuda.device(self.device):
+            _lib.call('dsen2_model_time_body_conv', self._handle, layer, _ptr(x_in), _ptr(aux), _ptr(out), n, h, w,
+                      iters, _stream_ptr(self.device), ctypes.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.load().dsen2_model_destroy(self._handle)
+                self._handle = ctypes.c_void_p(0)
+        except Exception:
+            pass
+
+
+def s2model(input_shape, num_layers=32, feature_size=256, device=None):
+    """utils/DSen2Net.py:18 — same positional arguments and defaults."""
+    return S2Model(input_shape, num_layers, feature_size, device=device)
+
+
+def conv3x3_nhwc(x, kernel_hwio, bias, epilogue=0, aux=None, res_scale=RES_SCALE):
+    """Single-layer entry point (kernel-level parity tests): x NHWC float32 CUDA tensor."""
+    n, h, w, cin = x.shape
+    kernel_hwio = np.ascontiguousarray(kernel_hwio, np.float32)
+    bias = np.ascontiguousarray(bias, np.float32)
+    cout = kernel_hwio.shape[3]
+    if epilogue == 2:
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call('dsen2_conv3x3_nhwc', _ptr(x), kernel_hwio.ctypes.data_as(_lib.c_float_p),
+                  bias.ctypes.data_as(_lib.c_float_p), _ptr(aux), _ptr(out), n, h, w, cin, cout, int(epilogue),
+                  float(res_scale), _stream_ptr(x.device))
+    return out

@@ -1,0 +1,76 @@
+"""ctypes binding of libdsen2_hip.so (the C ABI declared in include/dsen2_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  Nothing in this package computes on the CPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdsen2_hip.so')
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NO_WEIGHTS, ERR_WORKSPACE, ERR_NO_DEVICE = -1, -2, -3, -4, -5
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/dsen2_hip.h declares
+SIGNATURES = {
+    'dsen2_version': (ctypes.c_char_p, []),
+    'dsen2_last_error': (ctypes.c_char_p, []),
+    'dsen2_device_count': (c_int, []),
+    'dsen2_model_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int]),
+    'dsen2_model_destroy': (None, [c_void_p]),
+    'dsen2_model_num_params': (c_size_t, [c_void_p]),
+    'dsen2_model_load_weights': (c_int, [c_void_p, c_float_p, c_size_t]),
+    'dsen2_model_workspace_bytes': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
+    'dsen2_model_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_void_p, c_size_t, c_void_p]),
+    'dsen2_conv3x3_nhwc': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, ctypes.c_float, c_void_p]),
+    'dsen2_model_time_body_conv': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_float_p]),
+    'dsen2_upsample_mirror_bilinear': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float,
+                                               c_void_p]),
+    'dsen2_tile_gather': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float,
+                                  c_void_p, c_void_p]),
+    'dsen2_recompose': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float,
+                                c_void_p]),
+}
+
+_lib = None
+
+
+class DSen2Error(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__('libdsen2_hip error %d: %s' % (code, message))
+        self.code = code
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built — no CPU fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('%s not found: build it with `python -m dsen2_amd.build` (hipcc, gfx950). '
+                              'dsen2_amd has no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(code):
+    if code != OK:
+        raise DSen2Error(code, load().dsen2_last_error().decode('utf-8', 'replace'))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

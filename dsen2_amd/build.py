@@ -1,0 +1,39 @@
+"""Build libdsen2_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m dsen2_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['conv3x3_mfma.hip', 'patch_ops.hip', 'capi.hip']
+HEADERS = [os.path.join(CSRC, 'dsen2_internal.h'), os.path.join(os.path.dirname(HERE), 'include', 'dsen2_hip.h')]
+LIB = os.path.join(HERE, 'libdsen2_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-gpu-rdc',
+         '-Wall', '-Wno-unused-function']
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB + '.tmp']
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + '.tmp', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,306 @@
+// capi.hip — the extern "C" boundary of libdsen2_hip.so (declared in include/dsen2_hip.h).
+// Host-side orchestration only: argument checks, weight packing/upload, workspace carving and the
+// launch sequence of one forward pass.  No torch types, no allocation inside the forward path.
+#include "../../include/dsen2_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "dsen2_internal.h"
+
+using namespace dsen2;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(DSEN2_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct Layer {
+  int cin, cout;        // real channel counts (keras)
+  int epilogue;
+  PackGeom geom;
+  size_t w_off, b_off;  // float offsets inside dev_params
+  size_t flat_off;      // float offset of the kernel inside the keras-flat array
+};
+
+constexpr size_t kAlignFloats = 64;   // 256-byte alignment of every device sub-buffer
+size_t align_up(size_t v) { return (v + kAlignFloats - 1) / kAlignFloats * kAlignFloats; }
+
+}  // namespace
+
+struct dsen2_model {
+  int c10, c20, c60, cin, cout, num_layers, feat, precision;
+  int device;
+  std::vector<Layer> layers;
+  size_t n_params;
+  size_t dev_param_floats;
+  float* dev_params;
+  bool loaded;
+};
+
+extern "C" {
+
+const char* dsen2_version(void) { return "dsen2_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+const char* dsen2_last_error(void) { return g_err; }
+
+int dsen2_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(DSEN2_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  int good = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++good;
+  }
+  return good;
+}
+
+int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_layers, int feature_size,
+                       int precision) {
+  if (!out) return fail(DSEN2_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (c10 <= 0 || c20 <= 0 || c60 < 0 || num_layers < 0) return fail(DSEN2_ERR_INVALID, "bad channel/layer counts");
+  if (feature_size != 128 && feature_size != 256)
+    return fail(DSEN2_ERR_INVALID, "feature_size %d unsupported (128 or 256)", feature_size);
+  if (precision != 0) return fail(DSEN2_ERR_INVALID, "precision %d not built (0 = fp32)", precision);
+  const int cin = c10 + c20 + c60;
+  const int cout = c60 > 0 ? c60 : c20;   // utils/DSen2Net.py:35 — input_shape[-1][0]
+  if (cin > 16) return fail(DSEN2_ERR_INVALID, "%d input channels > 16", cin);
+  if (cout > 32) return fail(DSEN2_ERR_INVALID, "%d output channels > 32", cout);
+  dsen2_model* m = new (std::nothrow) dsen2_model();
+  if (!m) return fail(DSEN2_ERR_INVALID, "out of host memory");
+  m->c10 = c10; m->c20 = c20; m->c60 = c60; m->cin = cin; m->cout = cout;
+  m->num_layers = num_layers; m->feat = feature_size; m->precision = precision;
+  m->dev_params = nullptr; m->loaded = false;
+  if (hipGetDevice(&m->device) != hipSuccess) {
+    delete m;
+    return fail(DSEN2_ERR_NO_DEVICE, "no HIP device");
+  }
+  // graph order of utils/DSen2Net.py:29-35
+  std::vector<std::pair<int, int>> shapes;
+  std::vector<int> epis;
+  shapes.push_back({cin, feature_size}); epis.push_back(kEpiRelu);
+  for (int i = 0; i < num_layers; ++i) {
+    shapes.push_back({feature_size, feature_size}); epis.push_back(kEpiRelu);
+    shapes.push_back({feature_size, feature_size}); epis.push_back(kEpiResidual);
+  }
+  shapes.push_back({feature_size, cout}); epis.push_back(kEpiSkipNCHW);
+  size_t flat = 0, dev = 0;
+  for (size_t i = 0; i < shapes.size(); ++i) {
+    Layer L;
+    L.cin = shapes[i].first; L.cout = shapes[i].second; L.epilogue = epis[i];
+    if (!conv_pack_geometry(L.cin, L.cout, L.epilogue, &L.geom)) {
+      delete m;
+      return fail(DSEN2_ERR_INVALID, "no kernel for conv %d->%d", L.cin, L.cout);
+    }
+    L.flat_off = flat;
+    flat += (size_t)9 * L.cin * L.cout + L.cout;
+    L.w_off = dev; dev += align_up(packed_weight_floats(L.geom));
+    L.b_off = dev; dev += align_up((size_t)L.geom.cout_pad);
+    m->layers.push_back(L);
+  }
+  m->n_params = flat;
+  m->dev_param_floats = dev;
+  *out = m;
+  return DSEN2_OK;
+}
+
+void dsen2_model_destroy(dsen2_model* m) {
+  if (!m) return;
+  if (m->dev_params) (void)hipFree(m->dev_params);
+  delete m;
+}
+
+size_t dsen2_model_num_params(const dsen2_model* m) { return m ? m->n_params : 0; }
+
+int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t count) {
+  if (!m || !host_flat) return fail(DSEN2_ERR_INVALID, "NULL argument");
+  if (count != m->n_params)
+    return fail(DSEN2_ERR_INVALID, "expected %zu parameters, got %zu", m->n_params, count);
+  std::vector<float> staged(m->dev_param_floats, 0.f);
+  for (const Layer& L : m->layers) {
+    const float* k = host_flat + L.flat_off;
+    const float* b = k + (size_t)9 * L.cin * L.cout;
+    pack_conv_weights_host(k, L.cin, L.cout, L.geom, staged.data() + L.w_off);
+    memcpy(staged.data() + L.b_off, b, sizeof(float) * L.cout);
+  }
+  if (!m->dev_params) HIP_TRY(hipMalloc((void**)&m->dev_params, m->dev_param_floats * sizeof(float)));
+  HIP_TRY(hipMemcpy(m->dev_params, staged.data(), m->dev_param_floats * sizeof(float), hipMemcpyHostToDevice));
+  m->loaded = true;
+  return DSEN2_OK;
+}
+
+int dsen2_model_workspace_bytes(const dsen2_model* m, int n, int h, int w, size_t* bytes) {
+  if (!m || !bytes || n <= 0 || h <= 0 || w <= 0) return fail(DSEN2_ERR_INVALID, "bad argument");
+  const size_t pix = (size_t)n * h * w;
+  *bytes = (align_up(pix * 16) + 2 * align_up(pix * m->feat)) * sizeof(float);
+  return DSEN2_OK;
+}
+
+static int check_shape(const dsen2_model* m, int n, int h, int w) {
+  if (n <= 0 || h <= 0 || w <= 0) return fail(DSEN2_ERR_INVALID, "bad shape n=%d h=%d w=%d", n, h, w);
+  if ((size_t)h * w * (size_t)(m ? m->feat : 256) >= ((size_t)1 << 31))
+    return fail(DSEN2_ERR_INVALID, "one image of %dx%d exceeds 2^31 activation elements", h, w);
+  return DSEN2_OK;
+}
+
+static ConvParams make_params(const float* in, const float* wpk, const float* bias, const float* aux, float* out,
+                              int n, int h, int w, int cout_real, float scale) {
+  ConvParams p;
+  p.in = in; p.wpk = wpk; p.bias = bias; p.aux = aux; p.out = out;
+  p.n = n; p.h = h; p.w = w;
+  p.tiles_x = (w + kTile - 1) / kTile; p.tiles_y = (h + kTile - 1) / kTile;
+  p.cout_real = cout_real; p.res_scale = scale;
+  return p;
+}
+
+int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
+                        int h, int w, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!m || !x10 || !x20 || !out || !workspace) return fail(DSEN2_ERR_INVALID, "NULL argument");
+  if ((m->c60 > 0) != (x60 != nullptr)) return fail(DSEN2_ERR_INVALID, "x60 must be given iff the model has a 60 m input");
+  if (!m->loaded) return fail(DSEN2_ERR_NO_WEIGHTS, "dsen2_model_load_weights has not been called");
+  int rc = check_shape(m, n, h, w);
+  if (rc) return rc;
+  size_t need = 0;
+  dsen2_model_workspace_bytes(m, n, h, w, &need);
+  if (workspace_bytes < need) return fail(DSEN2_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t pix = (size_t)n * h * w;
+  float* x0 = (float*)workspace;                 // NHWC16 packed input
+  float* a = x0 + align_up(pix * 16);            // residual stream x
+  float* t = a + align_up(pix * m->feat);        // relu(convA(x))
+  const float* P = m->dev_params;
+  const float* skip = m->c60 > 0 ? x60 : x20;    // utils/DSen2Net.py:38,41
+
+  HIP_TRY(launch_pack_inputs(x10, x20, x60, m->c10, m->c20, m->c60, x0, n, h, w, stream));
+  size_t li = 0;
+  {
+    const Layer& L = m->layers[li++];            // DSen2Net.py:29
+    HIP_TRY(launch_conv3x3(make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f), L.geom.cin_pad,
+                           L.geom.cout_pad, L.epilogue, stream));
+  }
+  for (int i = 0; i < m->num_layers; ++i) {      // DSen2Net.py:31-32 -> :9-15
+    const Layer& LA = m->layers[li++];
+    HIP_TRY(launch_conv3x3(make_params(a, P + LA.w_off, P + LA.b_off, nullptr, t, n, h, w, 0, 0.f), LA.geom.cin_pad,
+                           LA.geom.cout_pad, LA.epilogue, stream));
+    const Layer& LB = m->layers[li++];
+    // in place on the residual stream: every workgroup reads aux and writes out at its own pixels only
+    HIP_TRY(launch_conv3x3(make_params(t, P + LB.w_off, P + LB.b_off, a, a, n, h, w, 0, 0.1f), LB.geom.cin_pad,
+                           LB.geom.cout_pad, LB.epilogue, stream));
+  }
+  {
+    const Layer& L = m->layers[li++];            // DSen2Net.py:35,38,41
+    HIP_TRY(launch_conv3x3(make_params(a, P + L.w_off, P + L.b_off, skip, out, n, h, w, m->cout, 0.f), L.geom.cin_pad,
+                           L.geom.cout_pad, L.epilogue, stream));
+  }
+  return DSEN2_OK;
+}
+
+int dsen2_conv3x3_nhwc(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
+                       float* dev_out, int n, int h, int w, int cin, int cout, int epilogue, float res_scale,
+                       void* stream_) {
+  if (!dev_in || !host_kernel || !host_bias || !dev_out) return fail(DSEN2_ERR_INVALID, "NULL argument");
+  if (epilogue != kEpiRelu && !dev_aux) return fail(DSEN2_ERR_INVALID, "epilogue %d needs dev_aux", epilogue);
+  int rc = check_shape(nullptr, n, h, w);
+  if (rc) return rc;
+  PackGeom g;
+  if (!conv_pack_geometry(cin, cout, epilogue, &g) || g.cin_pad != cin)
+    return fail(DSEN2_ERR_INVALID, "unsupported conv %d->%d epilogue %d", cin, cout, epilogue);
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t wf = packed_weight_floats(g);
+  std::vector<float> staged(wf + g.cout_pad, 0.f);
+  pack_conv_weights_host(host_kernel, cin, cout, g, staged.data());
+  memcpy(staged.data() + wf, host_bias, sizeof(float) * cout);
+  float* dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev, staged.size() * sizeof(float)));
+  hipError_t e = hipMemcpy(dev, staged.data(), staged.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = launch_conv3x3(make_params(dev_in, dev, dev + wf, dev_aux, dev_out, n, h, w, cout, res_scale), g.cin_pad,
+                       g.cout_pad, epilogue, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "conv3x3 launch: %s", hipGetErrorString(e));
+  return DSEN2_OK;
+}
+
+int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, const float* dev_aux, float* dev_out,
+                               int n, int h, int w, int iters, void* stream_, float* ms_per_launch) {
+  if (!m || !dev_in || !dev_out || !ms_per_launch || iters <= 0) return fail(DSEN2_ERR_INVALID, "bad argument");
+  if (!m->loaded) return fail(DSEN2_ERR_NO_WEIGHTS, "weights not loaded");
+  if (layer < 1 || layer > 2 * m->num_layers) return fail(DSEN2_ERR_INVALID, "layer %d out of range", layer);
+  int rc = check_shape(m, n, h, w);
+  if (rc) return rc;
+  const Layer& L = m->layers[layer];
+  if (L.epilogue == kEpiResidual && !dev_aux) return fail(DSEN2_ERR_INVALID, "residual layer needs dev_aux");
+  hipStream_t stream = (hipStream_t)stream_;
+  const float* P = m->dev_params;
+  const ConvParams p = make_params(dev_in, P + L.w_off, P + L.b_off, dev_aux, dev_out, n, h, w, 0, 0.1f);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(launch_conv3x3(p, L.geom.cin_pad, L.geom.cout_pad, L.epilogue, stream));   // warm-up
+  HIP_TRY(hipEventRecord(e0, stream));
+  for (int i = 0; i < iters; ++i) HIP_TRY(launch_conv3x3(p, L.geom.cin_pad, L.geom.cout_pad, L.epilogue, stream));
+  HIP_TRY(hipEventRecord(e1, stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / iters;
+  return DSEN2_OK;
+}
+
+int dsen2_upsample_mirror_bilinear(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow,
+                                   float post_divisor, void* stream) {
+  if (!dev_in || !dev_out || planes < 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || post_divisor == 0.f)
+    return fail(DSEN2_ERR_INVALID, "bad argument");
+  if ((size_t)h * w >= ((size_t)1 << 31) || (size_t)oh * ow >= ((size_t)1 << 31))
+    return fail(DSEN2_ERR_INVALID, "plane too large");
+  if (planes == 0) return DSEN2_OK;
+  HIP_TRY(launch_upsample(dev_in, dev_out, planes, h, w, oh, ow, post_divisor, (hipStream_t)stream));
+  return DSEN2_OK;
+}
+
+int dsen2_tile_gather(const float* dev_img, int H, int W, int C, int border, const int* dev_origins, int count, int P,
+                      float divisor, float* dev_patches, void* stream) {
+  if (!dev_img || !dev_patches || (!dev_origins && count > 0) || H <= 0 || W <= 0 || C <= 0 || border < 0 ||
+      count < 0 || P <= 0 || divisor == 0.f)
+    return fail(DSEN2_ERR_INVALID, "bad argument");
+  if (border > H || border > W) return fail(DSEN2_ERR_INVALID, "border %d larger than the image", border);
+  if ((size_t)C * P * P >= ((size_t)1 << 31)) return fail(DSEN2_ERR_INVALID, "patch too large");
+  HIP_TRY(launch_tile_gather(dev_img, H, W, C, border, dev_origins, count, P, divisor, dev_patches, (hipStream_t)stream));
+  return DSEN2_OK;
+}
+
+int dsen2_recompose(const float* dev_patches, int count, int C, int P, int border, float* dev_img, int H, int W,
+                    float scale, void* stream) {
+  if (!dev_patches || !dev_img || count <= 0 || C <= 0 || P <= 0 || border < 0 || H <= 0 || W <= 0)
+    return fail(DSEN2_ERR_INVALID, "bad argument");
+  hipError_t e = launch_recompose(dev_patches, count, C, P, border, dev_img, H, W, scale, (hipStream_t)stream);
+  if (e == hipErrorInvalidValue)
+    return fail(DSEN2_ERR_INVALID, "recompose geometry: count=%d P=%d border=%d H=%d W=%d", count, P, border, H, W);
+  if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "recompose launch: %s", hipGetErrorString(e));
+  return DSEN2_OK;
+}
+
+}  // extern "C"

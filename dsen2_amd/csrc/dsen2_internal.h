@@ -1,0 +1,62 @@
+// Internal declarations shared by the HIP translation units of libdsen2_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dsen2 {
+
+// ---- data layout ------------------------------------------------------------------------------
+// Activations inside the network: NHWC float32, [n][y][x][c], c contiguous (512 B per pixel at F=128).
+// Packed conv weights (one buffer per Conv2D):
+//   wpk[slab][cc][tap][g][o][j]  float32
+//     slab : output-channel slab of NT channels handled by one workgroup      (COUT_PAD / NT)
+//     cc   : input-channel chunk of KC channels                               (CIN_PAD / KC)
+//     tap  : dy*3 + dx                                                        (9)
+//     g    : group of 4 input channels inside the chunk                       (KC / 4)
+//     o    : output channel inside the slab                                   (NT)
+//     j    : input channel inside the group                                   (4)
+//   value = K_hwio[dy][dx][cc*KC + 4g + j][slab*NT + o]   (0 where the index is padding)
+// so one (slab, cc, tap) chunk is KC*NT contiguous floats that are copied verbatim into LDS, and one
+// ds_read_b128 at [g][o] hands a lane the 4 A-operand values W[o][4g .. 4g+3].
+
+constexpr int kTile = 16;                 // output pixels per workgroup edge (16 x 16 tile)
+constexpr int kHalo = kTile + 2;          // 18
+constexpr int kHaloPix = kHalo * kHalo;   // 324
+constexpr int kThreads = 512;             // 8 waves: 2 per SIMD
+
+enum Epilogue : int { kEpiRelu = 0, kEpiResidual = 1, kEpiSkipNCHW = 2 };
+
+struct ConvParams {
+  const float* in;     // NHWC [n][h][w][CIN_PAD]
+  const float* wpk;    // packed weights (layout above)
+  const float* bias;   // [COUT_PAD]
+  const float* aux;    // kEpiResidual: NHWC [n][h][w][COUT]; kEpiSkipNCHW: NCHW [n][cout_real][h][w]
+  float* out;          // NHWC [n][h][w][COUT] or NCHW [n][cout_real][h][w]
+  int n, h, w;
+  int tiles_x, tiles_y;
+  int cout_real;       // kEpiSkipNCHW only
+  float res_scale;     // kEpiResidual only
+};
+
+// Supported (CIN_PAD, COUT_PAD, epilogue) combinations; returns hipErrorInvalidValue otherwise.
+hipError_t launch_conv3x3(const ConvParams& p, int cin_pad, int cout_pad, int epilogue, hipStream_t stream);
+// Geometry helpers for packing
+struct PackGeom { int kc, nt, cin_pad, cout_pad; };
+bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g);
+size_t packed_weight_floats(const PackGeom& g);
+// host_kernel HWIO (3,3,cin,cout) -> packed layout (host memory, zero padded)
+void pack_conv_weights_host(const float* kernel_hwio, int cin, int cout, const PackGeom& g, float* dst);
+
+// ---- elementwise / gather kernels (patch_ops.hip) ---------------------------------------------
+// concat(x10,x20,x60) NCHW -> NHWC with 16 channels (zero padded): folds keras Concatenate(axis=1).
+hipError_t launch_pack_inputs(const float* x10, const float* x20, const float* x60, int c10, int c20, int c60,
+                              float* out_nhwc16, int n, int h, int w, hipStream_t stream);
+hipError_t launch_upsample(const float* in, float* out, int planes, int h, int w, int oh, int ow, float post_div,
+                           hipStream_t stream);
+hipError_t launch_tile_gather(const float* img, int H, int W, int C, int border, const int* origins, int count,
+                              int P, float divisor, float* patches, hipStream_t stream);
+hipError_t launch_recompose(const float* patches, int count, int C, int P, int border, float* img, int H, int W,
+                            float scale, hipStream_t stream);
+
+}  // namespace dsen2

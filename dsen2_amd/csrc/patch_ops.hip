@@ -1,0 +1,163 @@
+// patch_ops.hip — the HBM-bound kernels either side of the network: input concat/pack, mirror-bilinear
+// up-sampling, overlapped tiling and recomposition (utils/patches.py of the reference).
+// All of them are pure gathers: one thread per OUTPUT element, so there are no write races and every
+// store is coalesced; reads are served by L2 (each source line is touched by a handful of neighbours).
+#include "dsen2_internal.h"
+
+namespace dsen2 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline unsigned grid_for(size_t work, int block) {
+  size_t g = (work + block - 1) / block;
+  const size_t cap = 256 * 16;   // 256 CUs x 16 blocks, grid-stride the rest
+  return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+
+// ---- concat + NCHW -> NHWC16 ------------------------------------------------------------------
+// keras Concatenate(axis=1) of [input10, input20(, input60)] (utils/DSen2Net.py:24,26) folded into the
+// layout change the first convolution needs: out[n][y][x][0..15] = (x10 | x20 | x60 | zeros).
+__global__ __launch_bounds__(256) void pack_inputs_kernel(const float* __restrict__ x10, const float* __restrict__ x20,
+                                                          const float* __restrict__ x60, int c10, int c20, int c60,
+                                                          float* __restrict__ out, size_t npix_total, size_t plane) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix_total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / plane, q = i - n * plane;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float t = 0.f;
+      if (c < c10) t = x10[(n * c10 + c) * plane + q];
+      else if (c < c10 + c20) t = x20[(n * c20 + (c - c10)) * plane + q];
+      else if (c < c10 + c20 + c60) t = x60[(n * c60 + (c - c10 - c20)) * plane + q];
+      v[c] = t;
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(out + i * 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+  }
+}
+
+hipError_t launch_pack_inputs(const float* x10, const float* x20, const float* x60, int c10, int c20, int c60,
+                              float* out, int n, int h, int w, hipStream_t stream) {
+  const size_t plane = (size_t)h * w, total = plane * n;
+  hipLaunchKernelGGL(pack_inputs_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, x10, x20, x60, c10, c20,
+                     c60, out, total, plane);
+  return hipGetLastError();
+}
+
+// ---- mirror-bilinear up-sampling (interp_patches, utils/patches.py:11-16) ----------------------
+// skimage.transform.resize(x/30000, (oh,ow), mode='reflect')*30000, order 1:
+//   src = scale*dst + offset with scale = in/out, offset = 0.5*scale - 0.5, evaluated in float32 with a
+//   separate multiply and add exactly as skimage 0.18.3 does (warp() casts its matrix to the image dtype);
+//   neighbours floor(src)/ceil(src), folded back by mirroring WITHOUT repeating the edge sample;
+//   the blend itself is done in float64 and rounded once to float32.
+__device__ __forceinline__ int mirror_index(int i, int dim) {
+  if (dim == 1) return 0;
+  const int cmax = dim - 1;
+  if (i < 0) {
+    const int k = -i;
+    return ((k / cmax) & 1) ? cmax - (k % cmax) : (k % cmax);
+  }
+  if (i > cmax) return ((i / cmax) & 1) ? cmax - (i % cmax) : (i % cmax);
+  return i;
+}
+
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                       size_t total, int h, int w, int oh, int ow, float sy,
+                                                       float oy, float sx, float ox, float post_div) {
+  const size_t oplane = (size_t)oh * ow;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / oplane;
+    const int rem = (int)(i - p * oplane);
+    const int oi = rem / ow, oj = rem - oi * ow;
+    const float r = __fadd_rn(__fmul_rn(sy, (float)oi), oy);
+    const float c = __fadd_rn(__fmul_rn(sx, (float)oj), ox);
+    const float rf = floorf(r), cf = floorf(c);
+    const int r0 = mirror_index((int)rf, h), r1 = mirror_index((int)ceilf(r), h);
+    const int c0 = mirror_index((int)cf, w), c1 = mirror_index((int)ceilf(c), w);
+    const double dr = (double)__fsub_rn(r, rf), dc = (double)__fsub_rn(c, cf);
+    const float* src = in + p * (size_t)h * w;
+    const double tl = (double)__fdiv_rn(src[r0 * w + c0], 30000.0f), tr = (double)__fdiv_rn(src[r0 * w + c1], 30000.0f);
+    const double bl = (double)__fdiv_rn(src[r1 * w + c0], 30000.0f), br = (double)__fdiv_rn(src[r1 * w + c1], 30000.0f);
+    const double top = (1.0 - dc) * tl + dc * tr;
+    const double bot = (1.0 - dc) * bl + dc * br;
+    const float v = __fmul_rn((float)((1.0 - dr) * top + dr * bot), 30000.0f);
+    out[i] = post_div == 1.0f ? v : __fdiv_rn(v, post_div);   // folds `p20 /= SCALE` (testing/supres.py:24)
+  }
+}
+
+hipError_t launch_upsample(const float* in, float* out, int planes, int h, int w, int oh, int ow, float post_div,
+                           hipStream_t stream) {
+  const size_t total = (size_t)planes * oh * ow;
+  const double fy = (double)h / oh, fx = (double)w / ow;
+  hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, in, out, total, h, w, oh, ow,
+                     (float)fy, (float)(0.5 * fy - 0.5), (float)fx, (float)(0.5 * fx - 0.5), post_div);
+  return hipGetLastError();
+}
+
+// ---- overlapped tiling (get_test_patches{,60}: np.pad 'symmetric' + crop + HWC->CHW) -----------
+// numpy 'symmetric' pad repeats the edge sample: padded index q maps to |q - b| - (q < b) ... written out:
+__device__ __forceinline__ int symmetric_index(int q, int n) {   // q = index in the image frame, may be <0 or >=n
+  if (q < 0) q = -1 - q;
+  if (q >= n) q = 2 * n - 1 - q;
+  return q;
+}
+
+__global__ __launch_bounds__(256) void tile_gather_kernel(const float* __restrict__ img, int H, int W, int C,
+                                                          int border, const int* __restrict__ origins, size_t total,
+                                                          int P, float divisor, float* __restrict__ patches) {
+  const size_t pp = (size_t)P * P, per_patch = pp * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t k = i / per_patch;
+    const int rem = (int)(i - k * per_patch);
+    const int c = rem / (int)pp, r2 = rem - c * (int)pp;
+    const int y = r2 / P, x = r2 - y * P;
+    const int yy = symmetric_index(origins[2 * k] + y - border, H);
+    const int xx = symmetric_index(origins[2 * k + 1] + x - border, W);
+    const float v = img[((size_t)yy * W + xx) * C + c];
+    patches[i] = divisor == 1.0f ? v : __fdiv_rn(v, divisor);   // folds `p10 /= SCALE` (testing/supres.py:23)
+  }
+}
+
+hipError_t launch_tile_gather(const float* img, int H, int W, int C, int border, const int* origins, int count,
+                              int P, float divisor, float* patches, hipStream_t stream) {
+  const size_t total = (size_t)count * C * P * P;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(tile_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, img, H, W, C, border,
+                     origins, total, P, divisor, patches);
+  return hipGetLastError();
+}
+
+// ---- recomposition (recompose_images, utils/patches.py:374-405) --------------------------------
+__global__ __launch_bounds__(256) void recompose_kernel(const float* __restrict__ patches, int C, int P, int border,
+                                                        float* __restrict__ img, int H, int W, int x_tiles,
+                                                        int y_tiles, float scale, size_t total) {
+  const int inner = P - 2 * border;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+    // the LAST tile covering (y, x) wins, as in the reference's sequential overwrite
+    const int ty = (y >= H - inner) ? y_tiles - 1 : y / inner;
+    const int tx = (x >= W - inner) ? x_tiles - 1 : x / inner;
+    const int ys = (ty == y_tiles - 1) ? H - inner : ty * inner;
+    const int xs = (tx == x_tiles - 1) ? W - inner : tx * inner;
+    const size_t k = (size_t)ty * x_tiles + tx;
+    img[i] = patches[((k * C + c) * P + (border + y - ys)) * P + (border + x - xs)] * scale;
+  }
+}
+
+hipError_t launch_recompose(const float* patches, int count, int C, int P, int border, float* img, int H, int W,
+                            float scale, hipStream_t stream) {
+  const int inner = P - 2 * border;
+  if (inner <= 0 || H < inner || W < inner) return hipErrorInvalidValue;
+  const int x_tiles = (W + inner - 1) / inner, y_tiles = (H + inner - 1) / inner;
+  if ((long long)x_tiles * y_tiles > count) return hipErrorInvalidValue;
+  const size_t total = (size_t)H * W * C;
+  hipLaunchKernelGGL(recompose_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, patches, C, P, border, img, H,
+                     W, x_tiles, y_tiles, scale, total);
+  return hipGetLastError();
+}
+
+}  // namespace dsen2

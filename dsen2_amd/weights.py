@@ -1,0 +1,88 @@
+"""Weight containers for the DSen2 network.
+
+"keras flat" order (what dsen2_model_load_weights takes): for every Conv2D in graph order
+(utils/DSen2Net.py:29-35: conv_in, d x (convA, convB), conv_out) the kernel in keras' HWIO layout
+(3, 3, Cin, Cout) followed by the bias (Cout), all float32, concatenated.
+
+Files accepted by load_flat():
+  *.npy / *.npz['flat']   a flat array in that order (what tools/convert_keras_hdf5.py writes)
+  *.hdf5 / *.h5           a keras checkpoint as saved by training/supres_train.py:195-201 (needs h5py)
+"""
+import os
+
+import numpy as np
+
+
+def layer_shapes(cin, cout, num_layers, feature_size):
+    shapes = [(cin, feature_size)]
+    for _ in range(num_layers):
+        shapes += [(feature_size, feature_size)] * 2
+    shapes.append((feature_size, cout))
+    return shapes
+
+
+def num_params(cin, cout, num_layers, feature_size):
+    return sum(9 * a * b + b for a, b in layer_shapes(cin, cout, num_layers, feature_size))
+
+
+def random_he_uniform(cin, cout, num_layers, feature_size, seed=1, bias_scale=0.0):
+    """Random-init weights of the reference architecture (keras he_uniform: U(+-sqrt(6/(9*Cin))), zero bias)
+    for benchmarks and tests — the trained checkpoints are not redistributable with this repo."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parts = []
+    for a, b in layer_shapes(cin, cout, num_layers, feature_size):
+        limit = np.sqrt(6.0 / (9 * a))
+        parts.append(rng.uniform(-limit, limit, size=(3, 3, a, b)).astype(np.float32).ravel())
+        parts.append(rng.uniform(-bias_scale, bias_scale, size=(b,)).astype(np.float32) if bias_scale > 0
+                     else np.zeros((b,), np.float32))
+    return np.concatenate(parts)
+
+
+def _from_keras_hdf5(path, shapes):
+    try:
+        import h5py
+    except ImportError as e:   # pragma: no cover - depends on the host
+        raise ImportError('reading a keras .hdf5 checkpoint needs h5py; convert it once with '
+                          'tools/convert_keras_hdf5.py on a machine that has h5py and load the .npy') from e
+    parts = []
+    with h5py.File(path, 'r') as f:
+        root = f['model_weights'] if 'model_weights' in f else f
+        names = [n.decode() if isinstance(n, bytes) else n for n in root.attrs['layer_names']]
+        convs = []
+        for lname in names:
+            grp = root[lname]
+            wn = [n.decode() if isinstance(n, bytes) else n for n in grp.attrs.get('weight_names', [])]
+            if len(wn) == 2:
+                convs.append((np.asarray(grp[wn[0]]), np.asarray(grp[wn[1]])))
+        if len(convs) != len(shapes):
+            raise ValueError('%s holds %d conv layers, the architecture has %d' % (path, len(convs), len(shapes)))
+        for (k, b), (a, o) in zip(convs, shapes):
+            if k.shape != (3, 3, a, o) or b.shape != (o,):
+                raise ValueError('layer shape %s/%s does not match (3,3,%d,%d)' % (k.shape, b.shape, a, o))
+            parts += [k.astype(np.float32).ravel(), b.astype(np.float32)]
+    return np.concatenate(parts)
+
+
+def load_flat(path, cin, cout, num_layers, feature_size):
+    """Read a weight file into keras-flat order.  A missing file raises OSError like keras' load_weights."""
+    if not os.path.exists(path):
+        stem = os.path.splitext(path)[0]
+        for alt in (stem + '.npy', stem + '.npz'):
+            if os.path.exists(alt):
+                path = alt
+                break
+        else:
+            raise OSError('Unable to open file (name = %r)' % path)
+    shapes = layer_shapes(cin, cout, num_layers, feature_size)
+    ext = os.path.splitext(path)[1].lower()
+    if ext == '.npy':
+        flat = np.load(path)
+    elif ext == '.npz':
+        flat = np.load(path)['flat']
+    else:
+        flat = _from_keras_hdf5(path, shapes)
+    flat = np.ascontiguousarray(flat, np.float32).ravel()
+    want = num_params(cin, cout, num_layers, feature_size)
+    if flat.size != want:
+        raise ValueError('%s has %d parameters, the architecture needs %d' % (path, flat.size, want))
+    return flat

@@ -1,0 +1,124 @@
+/*
+ * dsen2_hip.h — C ABI of libdsen2_hip.so: the MI355X (gfx950) DSen2 / VDSen2 inference path.
+ *
+ * The reference (ACMEAtronOmatic/DSen2) is pure Python and has no FFI layer; the "operator API"
+ * below the drop-in boundary is keras' Model object.  Each entry point names the reference
+ * interface it stands in for (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C types only; every `const float* dev_*` / `float* dev_*` is a DEVICE pointer owned by
+ *     the caller (e.g. a PyTorch-ROCm tensor's data_ptr()); `host_*` pointers are host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is enqueued on
+ *     it; nothing synchronises unless stated.
+ *   - every function returns DSEN2_OK (0) or a negative error code and never throws;
+ *     dsen2_last_error() returns a thread-local description of the last failure.
+ *   - the library uses the calling thread's current HIP device; one model handle per device.
+ *   - activations handed across the ABI are NCHW float32 (the reference runs keras in
+ *     'channels_first', utils/DSen2Net.py:6); NHWC is internal.
+ */
+#ifndef DSEN2_HIP_H
+#define DSEN2_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSEN2_OK 0
+#define DSEN2_ERR_INVALID (-1)     /* bad argument / unsupported shape */
+#define DSEN2_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define DSEN2_ERR_NO_WEIGHTS (-3)  /* forward before load_weights */
+#define DSEN2_ERR_WORKSPACE (-4)   /* workspace too small */
+#define DSEN2_ERR_NO_DEVICE (-5)   /* no gfx950 device visible */
+
+typedef struct dsen2_model dsen2_model;
+
+const char *dsen2_version(void);
+const char *dsen2_last_error(void);
+/* Number of visible HIP devices whose gcnArchName starts with "gfx950"; <0 on error. */
+int dsen2_device_count(void);
+
+/* ---- network object -------------------------------------------------------------------------
+ * dsen2_model_create  <->  s2model(input_shape, num_layers, feature_size)   utils/DSen2Net.py:18-43
+ *   c10/c20/c60: channel counts of the 10 m / 20 m / 60 m inputs (c60 = 0 for the 2-input net).
+ *   The output has the channel count of the last input and that input is added back (:35-41).
+ *   feature_size must be a multiple of 128 (reference uses 128 and 256, testing/supres.py:56,59).
+ *   precision: 0 = fp32 everywhere (exact-f32 MFMA); 1 = bf16 operands, fp32 accumulate/residual.
+ */
+int dsen2_model_create(dsen2_model **out, int c10, int c20, int c60, int num_layers, int feature_size,
+                       int precision);
+void dsen2_model_destroy(dsen2_model *m);
+
+/* Number of float32 parameters in keras order (kernels HWIO (3,3,Cin,Cout) then bias, per Conv2D,
+ * in graph order: conv_in, d x (convA, convB), conv_out). */
+size_t dsen2_model_num_params(const dsen2_model *m);
+
+/* dsen2_model_load_weights  <->  model.load_weights(predict_file)        testing/supres.py:63
+ *   host_flat: `count` float32 in the order above (what a keras-HDF5 -> flat converter emits).
+ *   Packs into the MFMA operand layout and uploads; synchronises the device once. */
+int dsen2_model_load_weights(dsen2_model *m, const float *host_flat, size_t count);
+
+/* Scratch the caller must provide to dsen2_model_forward for a batch of n patches of h x w. */
+int dsen2_model_workspace_bytes(const dsen2_model *m, int n, int h, int w, size_t *bytes);
+
+/* dsen2_model_forward  <->  model.predict([p10, p20(, p60)])             testing/supres.py:65
+ *   dev_x10 [n,c10,h,w], dev_x20 [n,c20,h,w], dev_x60 [n,c60,h,w] or NULL, dev_out [n,cout,h,w];
+ *   all NCHW float32 device pointers, all at the same (already up-sampled) h x w. */
+int dsen2_model_forward(dsen2_model *m, const float *dev_x10, const float *dev_x20, const float *dev_x60,
+                        float *dev_out, int n, int h, int w, void *dev_workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* ---- single-layer entry points (kernel-level parity tests and benchmarks) -------------------
+ * One 3x3 'same' convolution (keras Conv2D as used at utils/DSen2Net.py:10,12,29,35) on NHWC
+ * float32 device tensors.  host_kernel is HWIO (3,3,cin,cout), host_bias is [cout].
+ *   epilogue 0: out = relu(conv + bias)                         DSen2Net.py:10-11 / :29
+ *   epilogue 1: out = dev_aux + res_scale * (conv + bias)       DSen2Net.py:12-15   (aux NHWC [n,h,w,cout])
+ *   epilogue 2: out = conv + bias + dev_aux, NCHW out and aux   DSen2Net.py:35,38,41 (aux/out [n,cout,h,w])
+ * cin must be a multiple of 16 (zero-pad channels), cout a multiple of 128 for epilogues 0/1 and
+ * <= 32 for epilogue 2.  Packs the weights on every call (test path, not the hot path). */
+int dsen2_conv3x3_nhwc(const float *dev_in, const float *host_kernel, const float *host_bias,
+                       const float *dev_aux, float *dev_out, int n, int h, int w, int cin, int cout,
+                       int epilogue, float res_scale, void *stream);
+
+/* Body-convolution micro-benchmark hook: runs `iters` launches of the 128->128 (or F->F) kernel on
+ * caller-provided NHWC buffers with already-packed weights held by `m` (layer index `layer`, 1-based
+ * body conv number) and reports the mean kernel time in milliseconds measured with HIP events on
+ * `stream`.  Used by bench.py for the roofline figure. */
+int dsen2_model_time_body_conv(dsen2_model *m, int layer, const float *dev_in, const float *dev_aux,
+                               float *dev_out, int n, int h, int w, int iters, void *stream,
+                               float *ms_per_launch);
+
+/* ---- tiling / up-sampling / recomposition (utils/patches.py) --------------------------------
+ * dsen2_upsample_mirror_bilinear  <->  interp_patches            utils/patches.py:11-16
+ *   planes x [h,w] -> planes x [oh,ow]; half-pixel-centre bilinear with mirror boundary (skimage
+ *   resize mode='reflect'), including the /30000 .. *30000 round trip.  The result is then divided by
+ *   `post_divisor` (1.0 = exact no-op, 2000 folds `p20 /= SCALE`, testing/supres.py:24). */
+int dsen2_upsample_mirror_bilinear(const float *dev_in, float *dev_out, int planes, int h, int w, int oh,
+                                   int ow, float post_divisor, void *stream);
+
+/* dsen2_tile_gather  <->  the pad + crop loops of get_test_patches{,60}   patches.py:27-28,58-72 / :93-95,127-143
+ *   dev_img: one HWC float32 image [H,W,C] (unpadded); writes patches [count,C,P,P] NCHW where patch k
+ *   has its origin at (dev_origins[2k], dev_origins[2k+1]) in PADDED coordinates (np.pad mode
+ *   'symmetric' by `border`, materialised on the fly).  Values are divided by `divisor`
+ *   (1.0 = exact copy, 2000 folds `p10 /= SCALE`, testing/supres.py:23; an IEEE float32 divide, so the
+ *   result is bit-identical to numpy's). */
+int dsen2_tile_gather(const float *dev_img, int H, int W, int C, int border, const int *dev_origins,
+                      int count, int P, float divisor, float *dev_patches, void *stream);
+
+/* dsen2_recompose  <->  recompose_images                          utils/patches.py:374-405
+ *   dev_patches [count,C,P,P] NCHW (the "a.shape[0] == 1 -> return a[0] uncropped" quirk of
+ *   patches.py:375-376 is a host-side transpose, not this function); writes the HWC image [H,W,C].  Tile grid as the
+ *   reference: inner = P - 2*border, x_tiles = ceil(W/inner), y_tiles = ceil(H/inner), row-major patch
+ *   order, last row/column origin clamped to size - inner.  The reference's sequential loop lets later
+ *   patches overwrite earlier ones where the clamped tile overlaps its neighbour; here every output
+ *   pixel reads the LAST patch that covers it, which is the same image without a write race.
+ *   Values are multiplied by `scale` (1.0, or 2000 to fold testing/supres.py:29).
+ *   Requires count >= x_tiles*y_tiles, H >= inner, W >= inner. */
+int dsen2_recompose(const float *dev_patches, int count, int C, int P, int border, float *dev_img, int H,
+                    int W, float scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSEN2_HIP_H */

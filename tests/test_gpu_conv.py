@@ -1,0 +1,112 @@
+"""Kernel-level parity: one HIP convolution (through the C ABI) vs the float64 C oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle                      # checker only
+from oracle import dsen2_oracle as do
+
+
+def _nhwc(x_nchw):
+    return torch.from_numpy(np.ascontiguousarray(x_nchw.transpose(0, 2, 3, 1))).cuda()
+
+
+def _rand(rng, shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+# fp32 MFMA = k-ordered fmaf chain: error ~1e-7 * sum|a*b|.  K = 9*Cin products of O(1)*O(0.1).
+def _tol(cin):
+    return 2e-6 * np.sqrt(9 * cin)
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [
+    (16, 128, 2, 32, 32),       # conv_in geometry (10 or 12 real channels zero-padded to 16)
+    (128, 128, 2, 32, 32),      # body conv, BASELINE config patch size
+    (128, 128, 1, 16, 16),      # single tile
+    (128, 128, 1, 21, 37),      # ragged: H, W not multiples of the 16x16 tile
+    (128, 128, 3, 48, 16),      # non-square, several tiles
+    (256, 256, 1, 32, 32),      # VDSen2 width: two output slabs, 8 channel chunks
+    (16, 256, 1, 19, 16),
+])
+def test_conv_relu_matches_oracle(cin, cout, n, h, w):
+    rng = np.random.default_rng(cin * 1000 + cout + h)
+    x = _rand(rng, (n, cin, h, w))
+    k = _rand(rng, (3, 3, cin, cout), np.sqrt(2.0 / (9 * cin)))
+    b = _rand(rng, (cout,), 0.1)
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    y = conv3x3_nhwc(_nhwc(x), k, b, epilogue=0).cpu().numpy().transpose(0, 3, 1, 2)
+    ref = c_oracle.conv3x3(x, k, b, relu=True)
+    assert np.abs(y - ref).max() < _tol(cin) * 4
+    assert do.rmse(y, ref) < _tol(cin)
+    assert (y >= 0).all()
+
+
+@pytest.mark.parametrize('feat,n,h,w', [(128, 2, 32, 32), (128, 1, 23, 18), (256, 1, 16, 32)])
+def test_conv_residual_matches_oracle(feat, n, h, w):
+    rng = np.random.default_rng(feat + h)
+    x = _rand(rng, (n, feat, h, w))
+    res = _rand(rng, (n, feat, h, w))
+    k = _rand(rng, (3, 3, feat, feat), np.sqrt(2.0 / (9 * feat)))
+    b = _rand(rng, (feat,), 0.1)
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    y = conv3x3_nhwc(_nhwc(x), k, b, epilogue=1, aux=_nhwc(res), res_scale=0.1).cpu().numpy().transpose(0, 3, 1, 2)
+    ref = res.astype(np.float64) + 0.1 * c_oracle.conv3x3(x, k, b, relu=False)     # DSen2Net.py:12-15
+    assert do.rmse(y, ref) < _tol(feat)
+
+
+def test_conv_residual_in_place():
+    """forward() runs conv-B in place on the residual stream (aux == out)."""
+    rng = np.random.default_rng(5)
+    x = _rand(rng, (1, 128, 32, 32)); res = _rand(rng, (1, 128, 32, 32))
+    k = _rand(rng, (3, 3, 128, 128), 0.05); b = _rand(rng, (128,), 0.1)
+    import ctypes
+    from dsen2_amd import _lib
+    xin, r = _nhwc(x), _nhwc(res)
+    _lib.call('dsen2_conv3x3_nhwc', ctypes.c_void_p(xin.data_ptr()), k.ctypes.data_as(_lib.c_float_p),
+              b.ctypes.data_as(_lib.c_float_p), ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(r.data_ptr()),
+              1, 32, 32, 128, 128, 1, 0.1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    ref = res.astype(np.float64) + 0.1 * c_oracle.conv3x3(x, k, b)
+    assert do.rmse(r.cpu().numpy().transpose(0, 3, 1, 2), ref) < _tol(128)
+
+
+@pytest.mark.parametrize('feat,cout,n,h,w', [(128, 6, 2, 32, 32), (128, 2, 1, 20, 35), (256, 6, 1, 16, 16)])
+def test_conv_out_skip_nchw_matches_oracle(feat, cout, n, h, w):
+    rng = np.random.default_rng(feat + cout)
+    x = _rand(rng, (n, feat, h, w))
+    skip = _rand(rng, (n, cout, h, w))
+    k = _rand(rng, (3, 3, feat, cout), np.sqrt(2.0 / (9 * feat)))
+    b = _rand(rng, (cout,), 0.1)
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    y = conv3x3_nhwc(_nhwc(x), k, b, epilogue=2, aux=torch.from_numpy(skip).cuda()).cpu().numpy()
+    ref = c_oracle.conv3x3(x, k, b) + skip                                         # DSen2Net.py:35,38,41
+    assert y.shape == (n, cout, h, w)
+    assert do.rmse(y, ref) < _tol(feat)
+
+
+def test_delta_kernel_shifts_exactly():
+    """Known-answer: a one-hot kernel copies a shifted input channel bit-exactly (zero outside)."""
+    rng = np.random.default_rng(9)
+    x = _rand(rng, (1, 128, 32, 32))
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    for dy, dx, ci, co in [(0, 0, 3, 5), (2, 1, 127, 0), (1, 1, 64, 127), (0, 2, 31, 32)]:
+        k = np.zeros((3, 3, 128, 128), np.float32); k[dy, dx, ci, co] = 1
+        # use the residual epilogue with zero aux and scale 1 so negatives survive
+        y = conv3x3_nhwc(_nhwc(x), k, np.zeros(128, np.float32), epilogue=1,
+                         aux=torch.zeros(1, 32, 32, 128, device='cuda'), res_scale=1.0).cpu().numpy()
+        exp = np.zeros((32, 32), np.float32)
+        ys = slice(max(0, 1 - dy), min(32, 33 - dy)); xs = slice(max(0, 1 - dx), min(32, 33 - dx))
+        exp[ys, xs] = x[0, ci, ys.start + dy - 1:ys.stop + dy - 1, xs.start + dx - 1:xs.stop + dx - 1]
+        assert np.array_equal(y[0, :, :, co], exp), (dy, dx, ci, co)
+        other = np.delete(y[0], co, axis=2)
+        assert not other.any()
+
+
+def test_bad_arguments_raise():
+    from dsen2_amd import _lib
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    x = torch.zeros(1, 8, 8, 24, device='cuda')
+    with pytest.raises(_lib.DSen2Error):
+        conv3x3_nhwc(x, np.zeros((3, 3, 24, 128), np.float32), np.zeros(128, np.float32))

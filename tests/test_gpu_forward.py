@@ -1,0 +1,100 @@
+"""Whole-network parity through the C ABI: dsen2_model_forward vs the float64 oracle.
+
+Gate: RMSE <= 1e-4 in the network's normalised domain for fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle
+from oracle import dsen2_oracle as do
+
+RMSE_GATE = 1e-4
+CNN_CASES = ['cnn_20_d6_f128', 'cnn_60_d6_f128', 'cnn_20_d2_f256', 'cnn_20_d6_f128_ragged']
+
+
+def _model(bands, d, f, flat):
+    from dsen2_amd.DSen2Net import s2model
+    m = s2model(tuple((b, None, None) for b in bands), num_layers=d, feature_size=f)
+    assert m.count_params() == flat.size
+    m.set_weights_flat(flat)
+    return m
+
+
+@pytest.mark.parametrize('name', CNN_CASES)
+def test_forward_matches_golden_fixture(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    bands = tuple(int(b) for b in g['bands'])
+    d, f = int(g['num_layers']), int(g['feature_size'])
+    flat = do.he_uniform_weights(sum(bands), bands[-1], d, f, seed=int(g['weight_seed']),
+                                 bias_scale=float(g['bias_scale']))
+    xs = [g['x%d' % i] for i in range(len(bands))]
+    y = _model(bands, d, f, flat).predict(xs)
+    assert y.dtype == np.float32 and y.shape == g['out'].shape
+    err = do.rmse(y, g['out'])
+    print(name, 'rmse', err, 'max', np.abs(y - g['out']).max())
+    assert err < RMSE_GATE
+    assert err < 5e-6              # what exact-f32 MFMA should actually achieve
+
+
+def test_forward_config_patch_vs_c_oracle():
+    """BASELINE configs[1] geometry (32x32x(4+6), d=6, F=128) at a batch the oracle finishes in seconds."""
+    flat = do.he_uniform_weights(10, 6, 6, 128, seed=1)
+    xs = do.synthetic_inputs(4, 32, 32, (4, 6), seed=0)
+    y = _model((4, 6), 6, 128, flat).predict(xs)
+    ref = c_oracle.forward(xs, flat, 6, 128)
+    assert do.rmse(y, ref) < 5e-6
+
+
+def test_forward_batching_is_invisible():
+    flat = do.he_uniform_weights(10, 6, 6, 128, seed=3)
+    xs = do.synthetic_inputs(5, 32, 32, (4, 6), seed=2)
+    m = _model((4, 6), 6, 128, flat)
+    a = m.predict(xs)
+    b = m.predict(xs, batch_size=2)
+    assert np.array_equal(a, b)
+
+
+def test_zero_weights_return_skip_input_exactly():
+    """Size-independent property: with all-zero parameters the network is the identity on its
+    low-resolution input (DSen2Net.py:38,41)."""
+    xs = do.synthetic_inputs(3, 32, 32, (4, 6, 2), seed=4)
+    m = _model((4, 6, 2), 6, 128, np.zeros(do.num_params(12, 2, 6, 128), np.float32))
+    assert np.array_equal(m.predict(xs), xs[2])
+
+
+def test_full_batch_512_properties():
+    """BASELINE configs[1] at full size (512 x 32x32): properties that need no oracle at that size,
+    plus an oracle check of a sampled subset."""
+    flat = do.he_uniform_weights(10, 6, 6, 128, seed=1)
+    xs = do.synthetic_inputs(512, 32, 32, (4, 6), seed=0)
+    m = _model((4, 6), 6, 128, flat)
+    dev = [torch.from_numpy(a).cuda() for a in xs]
+    y1 = m.forward_device(dev).clone()
+    y2 = m.forward_device(dev)
+    assert torch.equal(y1, y2)                                   # deterministic, bit for bit
+    perm = torch.randperm(512, generator=torch.Generator().manual_seed(0)).cuda()
+    yp = m.forward_device([d[perm].contiguous() for d in dev])
+    assert torch.equal(yp, y1[perm])                             # patches are independent units
+    y = y1.cpu().numpy()
+    assert np.isfinite(y).all()
+    idx = [0, 17, 255, 511]
+    ref = c_oracle.forward([a[idx] for a in xs], flat, 6, 128)
+    assert do.rmse(y[idx], ref) < 5e-6
+
+
+def test_forward_errors():
+    from dsen2_amd import _lib
+    from dsen2_amd.DSen2Net import s2model
+    m = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128)
+    x = [np.zeros((1, 4, 16, 16), np.float32), np.zeros((1, 6, 16, 16), np.float32)]
+    with pytest.raises(_lib.DSen2Error) as e:
+        m.predict(x)                                             # no weights loaded
+    assert e.value.code == _lib.ERR_NO_WEIGHTS
+    with pytest.raises(_lib.DSen2Error):
+        m.set_weights_flat(np.zeros(10, np.float32))             # wrong parameter count
+    with pytest.raises(_lib.DSen2Error):
+        s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=100)

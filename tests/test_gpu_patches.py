@@ -1,0 +1,120 @@
+"""GPU tiling / up-sampling / recomposition (through the C ABI) vs the reference's own outputs
+(tests/golden/*.npz captured from /root/reference/utils/patches.py) and vs the oracle."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import patches_oracle as po
+
+CASES20 = ['patches_20_div.npz', 'patches_20_nondiv.npz', 'patches_20_b8.npz']
+CASES60 = ['patches_60_div.npz', 'patches_60_nondiv.npz', 'patches_60_b12.npz']
+# The kernel uses skimage's float32 sample coordinates and a float64 blend: a few float32 ulp
+# (values <= 13110 -> ulp <= 9.8e-4) of the captured reference output.
+TIGHT = dict(rtol=4e-7, atol=2e-3)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize('name', CASES20)
+def test_get_test_patches(golden_dir, name):
+    from dsen2_amd import patches as gp
+    g = load(golden_dir, name)
+    d10, d20 = g['d10'].astype(np.float32), g['d20'].astype(np.float32)
+    patch, border = int(g['patch']), int(g['border'])
+    p10, p20 = gp.get_test_patches(d10, d20, patchSize=patch, border=border)
+    assert p10.dtype == np.float32 and p10.shape == g['p10'].shape
+    assert np.array_equal(p10, g['p10'])                         # bit-exact copy, incl. trailing zero patches
+    np.testing.assert_allclose(p20, g['p20'], **TIGHT)
+    _, raw = gp.get_test_patches(d10, d20, patchSize=patch, border=border, interp=False)
+    assert np.array_equal(raw, g['p20_raw'])
+    # accepts the integer dtype the tiles are stored in, like the reference (np.pad + float32 assignment)
+    q10, _ = gp.get_test_patches(g['d10'], g['d20'], patchSize=patch, border=border, interp=False)
+    assert np.array_equal(q10, g['p10'])
+
+
+@pytest.mark.parametrize('name', CASES60)
+def test_get_test_patches60(golden_dir, name):
+    from dsen2_amd import patches as gp
+    g = load(golden_dir, name)
+    d = [g[k].astype(np.float32) for k in ('d10', 'd20', 'd60')]
+    patch, border = int(g['patch']), int(g['border'])
+    p10, p20, p60 = gp.get_test_patches60(*d, patchSize=patch, border=border)
+    assert np.array_equal(p10, g['p10'])
+    np.testing.assert_allclose(p20, g['p20'], **TIGHT)
+    np.testing.assert_allclose(p60, g['p60'], **TIGHT)
+    _, r20, r60 = gp.get_test_patches60(*d, patchSize=patch, border=border, interp=False)
+    assert np.array_equal(r20, g['p20_raw']) and np.array_equal(r60, g['p60_raw'])
+
+
+@pytest.mark.parametrize('name', CASES20 + CASES60)
+def test_recompose(golden_dir, name):
+    from dsen2_amd import patches as gp
+    g = load(golden_dir, name)
+    rec = quiet(gp.recompose_images, g['pred'], border=int(g['border']), size=g['d10'].shape)
+    assert rec.dtype == np.float32 and np.array_equal(rec, g['rec'])
+
+
+def test_recompose_single_patch_quirk(golden_dir):
+    from dsen2_amd import patches as gp
+    g = load(golden_dir, 'recompose_single.npz')
+    rec = gp.recompose_images(g['pred'], border=4, size=(24, 24, 4))
+    assert np.array_equal(rec, g['rec'])
+
+
+def test_interp_patches(golden_dir):
+    from dsen2_amd import patches as gp
+    g = load(golden_dir, 'interp.npz')
+    for src, key in [('ramp', 'ramp_x2'), ('ramp', 'ramp_x6'), ('a', 'a_x2'), ('a', 'a_x6'), ('b', 'b_x2'),
+                     ('b', 'b_x6')]:
+        out = gp.interp_patches(g[src], g[key].shape)
+        assert out.dtype == np.float32
+        np.testing.assert_allclose(out, g[key], err_msg=key, **TIGHT)
+    ramp = gp.interp_patches(g['ramp'], (1, 1, 8, 8))[0, 0, 0]
+    np.testing.assert_allclose(ramp, [2.5, 2.5, 7.5, 12.5, 17.5, 22.5, 27.5, 27.5], rtol=1e-6)
+
+
+def test_real_tile_crop_default_geometry(golden_dir):
+    """128/8 and 192/12 (testing/supres.py:21-22,40-41) on the crop of the bundled T33UUB tile."""
+    from dsen2_amd import patches as gp
+    g = load(golden_dir, 'tile_T33UUB_crop.npz')
+    d = [g[k].astype(np.float32) for k in ('d10', 'd20', 'd60')]
+    sub = (slice(None), slice(None), slice(3, None, 7), slice(2, None, 5))
+    p10, p20 = gp.get_test_patches(d[0], d[1], patchSize=128, border=8)
+    assert p10.shape == (9, 4, 128, 128)
+    np.testing.assert_array_equal(p10.astype(np.float64).sum(axis=(2, 3)), g['p10_sum'])
+    np.testing.assert_allclose(p20[sub], g['p20_sub'], **TIGHT)
+    np.testing.assert_allclose(p20[4, :2], g['p20_patch4'], **TIGHT)
+    q10, q20, q60 = gp.get_test_patches60(*d, patchSize=192, border=12)
+    assert q10.shape == (4, 4, 192, 192)
+    np.testing.assert_array_equal(q10.astype(np.float64).sum(axis=(2, 3)), g['q10_sum'])
+    np.testing.assert_allclose(q20[sub], g['q20_sub'], **TIGHT)
+    np.testing.assert_allclose(q60[sub], g['q60_sub'], **TIGHT)
+    rec = quiet(gp.recompose_images, p10, border=8, size=d[0].shape)
+    assert np.array_equal(rec, d[0])                             # tiling -> recompose round trip
+
+
+def test_large_image_round_trip_and_oracle():
+    """Size-independent property at a production-like size: recompose(tile(x)) == x, and the GPU patches
+    equal the oracle's on a 1098x1098 image (a 10 % edge of a real 10980^2 tile)."""
+    from dsen2_amd import patches as gp
+    rng = np.random.default_rng(0)
+    d10 = rng.integers(35, 13110, size=(1098, 1098, 4)).astype(np.float32)
+    d20 = rng.integers(35, 13110, size=(549, 549, 6)).astype(np.float32)
+    p10, p20 = gp.get_test_patches(d10, d20, patchSize=128, border=8)
+    rec = quiet(gp.recompose_images, p10, border=8, size=d10.shape)
+    assert np.array_equal(rec, d10)
+    o10, o20 = po.get_test_patches(d10, d20, patchSize=128, border=8, f32_coords=True)
+    assert np.array_equal(p10, o10)
+    np.testing.assert_allclose(p20, o20, **TIGHT)

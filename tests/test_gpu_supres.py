@@ -1,0 +1,117 @@
+"""End-to-end drop-in surface: DSen2_20 / DSen2_60 / _predict (testing/supres.py) on the GPU vs the
+oracle pipeline (oracle tiling + float64 oracle CNN + oracle recomposition)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle
+from oracle import dsen2_oracle as do
+from oracle import patches_oracle as po
+
+RMSE_GATE_NORMALISED = 1e-4     # fp32 gate, in the network's normalised (/2000) domain
+
+
+@pytest.fixture()
+def model_dir(tmp_path, monkeypatch):
+    """A MDL_PATH holding synthetic checkpoints under the reference's file names (as .npy)."""
+    from dsen2_amd import supres
+    files = {}
+    for stem, (cin, cout, d, f, seed) in {
+        's2_032_lr_1e-04': (10, 6, 6, 128, 11), 's2_030_lr_1e-05': (12, 2, 6, 128, 12),
+        's2_033_lr_1e-04': (10, 6, 32, 256, 13), 's2_034_lr_1e-04': (12, 2, 32, 256, 14),
+    }.items():
+        if d == 32:
+            continue                        # VDSen2 oracle at float64 is too slow for a unit test
+        flat = do.he_uniform_weights(cin, cout, d, f, seed=seed, bias_scale=0.02)
+        np.save(str(tmp_path / (stem + '.npy')), flat)
+        files[stem] = flat
+    monkeypatch.setattr(supres, 'MDL_PATH', str(tmp_path) + os.sep)
+    supres.clear_model_cache()
+    yield files
+    supres.clear_model_cache()
+
+
+def quiet(fn, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = fn(*a, **k)
+    return out, buf.getvalue()
+
+
+def oracle_dsen2_20(d10, d20, flat):
+    p10, p20 = po.get_test_patches(d10, d20, patchSize=128, border=8, f32_coords=True)
+    p10 = p10 / np.float32(2000); p20 = p20 / np.float32(2000)
+    used = int(np.ceil(d10.shape[0] / 112.0) * np.ceil(d10.shape[1] / 112.0))
+    pred = np.zeros((p10.shape[0], 6, 128, 128))
+    pred[:used] = c_oracle.forward([p10[:used], p20[:used]], flat, 6, 128)
+    with contextlib.redirect_stdout(io.StringIO()):
+        img = po.recompose_images(pred, border=8, size=d10.shape)
+    return img.astype(np.float64) * 2000
+
+
+def test_dsen2_20_matches_oracle_pipeline(model_dir):
+    from dsen2_amd.supres import DSen2_20
+    rng = np.random.default_rng(1)
+    d10 = rng.integers(35, 6000, size=(240, 150, 4)).astype(np.float32)     # non-dividing: clamped last tiles
+    d20 = rng.integers(35, 6000, size=(120, 75, 6)).astype(np.float32)
+    keep10, keep20 = d10.copy(), d20.copy()
+    out, printed = quiet(DSen2_20, d10, d20, deep=False)
+    assert out.shape == (240, 150, 6) and out.dtype == np.float32
+    assert np.array_equal(d10, keep10) and np.array_equal(d20, keep20)      # caller's arrays untouched
+    assert 'Symbolic Model Created.' in printed and 's2_032_lr_1e-04.hdf5' in printed
+    ref = oracle_dsen2_20(d10, d20, model_dir['s2_032_lr_1e-04'])
+    err = do.rmse(out, ref) / 2000
+    print('DSen2_20 normalised rmse', err)
+    assert err < RMSE_GATE_NORMALISED
+
+
+def test_dsen2_60_matches_oracle_pipeline(model_dir):
+    from dsen2_amd.supres import DSen2_60
+    rng = np.random.default_rng(2)
+    d10 = rng.integers(35, 6000, size=(216, 180, 4)).astype(np.float32)
+    d20 = rng.integers(35, 6000, size=(108, 90, 6)).astype(np.float32)
+    d60 = rng.integers(35, 6000, size=(36, 30, 2)).astype(np.float32)
+    out, _ = quiet(DSen2_60, d10, d20, d60, deep=False)
+    assert out.shape == (216, 180, 2) and out.dtype == np.float32
+    flat = model_dir['s2_030_lr_1e-05']
+    p = po.get_test_patches60(d10, d20, d60, patchSize=192, border=12, f32_coords=True)
+    p = [a / np.float32(2000) for a in p]
+    used = int(np.ceil(216 / 168.0) * np.ceil(180 / 168.0))
+    pred = np.zeros((p[0].shape[0], 2, 192, 192))
+    pred[:used] = c_oracle.forward([a[:used] for a in p], flat, 6, 128)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = po.recompose_images(pred, border=12, size=d10.shape).astype(np.float64) * 2000
+    assert do.rmse(out, ref) / 2000 < RMSE_GATE_NORMALISED
+
+
+def test_predict_surface(model_dir):
+    """_predict(test, input_shape, deep, run_60): list of NCHW arrays in, NCHW float32 out, every patch
+    computed (trailing zero patches included, as keras would)."""
+    from dsen2_amd.supres import _predict
+    xs = do.synthetic_inputs(3, 32, 32, (4, 6), seed=8)
+    xs[0][2] = 0; xs[1][2] = 0
+    out, _ = quiet(_predict, xs, ((4, None, None), (6, None, None)))
+    ref = c_oracle.forward(xs, model_dir['s2_032_lr_1e-04'], 6, 128)
+    assert out.shape == (3, 6, 32, 32) and out.dtype == np.float32
+    assert do.rmse(out, ref) < 5e-6
+
+
+def test_image_smaller_than_a_patch_is_rejected(model_dir):
+    """The reference indexes with a negative origin and dies on a shape mismatch (patches.py:52,62-72);
+    here the same input raises ValueError before any GPU work."""
+    from dsen2_amd.supres import DSen2_20
+    with pytest.raises(ValueError):
+        quiet(DSen2_20, np.zeros((100, 100, 4), np.float32), np.zeros((50, 50, 6), np.float32))
+
+
+def test_missing_checkpoint_raises_oserror(tmp_path, monkeypatch):
+    from dsen2_amd import supres
+    monkeypatch.setattr(supres, 'MDL_PATH', str(tmp_path / 'nowhere') + os.sep)
+    supres.clear_model_cache()
+    with pytest.raises(OSError):
+        quiet(supres.DSen2_20, np.zeros((240, 240, 4), np.float32), np.zeros((120, 120, 6), np.float32))
