@@ -55,6 +55,10 @@ def load():
     """Load the shared library (once).  Raises if it has not been built — no CPU fallback exists."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the process's HIP runtime BEFORE this
+        # library is mapped, otherwise /opt/rocm's copy is loaded first, torch then brings a second runtime
+        # and the two do not share devices, streams or allocations ("no HIP device").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise ImportError('%s not found: build it with `python -m dsen2_amd.build` (hipcc, gfx950). '
                               'dsen2_amd has no CPU fallback.' % LIB_PATH)

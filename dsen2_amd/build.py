@@ -12,7 +12,9 @@ SOURCES = ['conv3x3_mfma.hip', 'patch_ops.hip', 'capi.hip']
 HEADERS = [os.path.join(CSRC, 'dsen2_internal.h'), os.path.join(os.path.dirname(HERE), 'include', 'dsen2_hip.h')]
 LIB = os.path.join(HERE, 'libdsen2_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-gpu-rdc',
+# -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators, so the default contraction would fuse the
+# up-sampler's `scale*dst + offset` (skimage rounds twice) and the residual epilogue's `x + 0.1*t` into FMAs.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-gpu-rdc', '-ffp-contract=off',
          '-Wall', '-Wno-unused-function']
 
 
