@@ -23,6 +23,7 @@ SIGNATURES = {
     'dsen2_version': (ctypes.c_char_p, []),
     'dsen2_last_error': (ctypes.c_char_p, []),
     'dsen2_device_count': (c_int, []),
+    'dsen2_set_tuning': (c_int, [c_int, c_int]),
     'dsen2_model_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int]),
     'dsen2_model_destroy': (None, [c_void_p]),
     'dsen2_model_num_params': (c_size_t, [c_void_p]),

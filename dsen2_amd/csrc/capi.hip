@@ -59,6 +59,19 @@ extern "C" {
 const char* dsen2_version(void) { return "dsen2_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
 const char* dsen2_last_error(void) { return g_err; }
 
+int dsen2_set_tuning(int key, int value) {
+  if (key == 0) {
+    if (value < 0 || value > 6) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
+    g_body_variant = value;
+    return DSEN2_OK;
+  }
+  if (key == 1) {   // timing-only ablation of the persistent body kernel (wrong results when non-zero)
+    g_body_ablate = value;
+    return DSEN2_OK;
+  }
+  return fail(DSEN2_ERR_INVALID, "unknown tuning key %d", key);
+}
+
 int dsen2_device_count(void) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -158,8 +171,8 @@ int dsen2_model_workspace_bytes(const dsen2_model* m, int n, int h, int w, size_
 
 static int check_shape(const dsen2_model* m, int n, int h, int w) {
   if (n <= 0 || h <= 0 || w <= 0) return fail(DSEN2_ERR_INVALID, "bad shape n=%d h=%d w=%d", n, h, w);
-  if ((size_t)h * w * (size_t)(m ? m->feat : 256) >= ((size_t)1 << 31))
-    return fail(DSEN2_ERR_INVALID, "one image of %dx%d exceeds 2^31 activation elements", h, w);
+  if ((size_t)h * w * (size_t)(m ? m->feat : 256) >= ((size_t)1 << 29))
+    return fail(DSEN2_ERR_INVALID, "one image of %dx%d exceeds 2^31 activation bytes", h, w);
   return DSEN2_OK;
 }
 
@@ -195,22 +208,18 @@ int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, cons
   size_t li = 0;
   {
     const Layer& L = m->layers[li++];            // DSen2Net.py:29
-    HIP_TRY(launch_conv3x3(make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f), L.geom.cin_pad,
-                           L.geom.cout_pad, L.epilogue, stream));
+    HIP_TRY(launch_conv3x3(make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f), L.geom, L.epilogue, stream));
   }
   for (int i = 0; i < m->num_layers; ++i) {      // DSen2Net.py:31-32 -> :9-15
     const Layer& LA = m->layers[li++];
-    HIP_TRY(launch_conv3x3(make_params(a, P + LA.w_off, P + LA.b_off, nullptr, t, n, h, w, 0, 0.f), LA.geom.cin_pad,
-                           LA.geom.cout_pad, LA.epilogue, stream));
+    HIP_TRY(launch_conv3x3(make_params(a, P + LA.w_off, P + LA.b_off, nullptr, t, n, h, w, 0, 0.f), LA.geom, LA.epilogue, stream));
     const Layer& LB = m->layers[li++];
     // in place on the residual stream: every workgroup reads aux and writes out at its own pixels only
-    HIP_TRY(launch_conv3x3(make_params(t, P + LB.w_off, P + LB.b_off, a, a, n, h, w, 0, 0.1f), LB.geom.cin_pad,
-                           LB.geom.cout_pad, LB.epilogue, stream));
+    HIP_TRY(launch_conv3x3(make_params(t, P + LB.w_off, P + LB.b_off, a, a, n, h, w, 0, 0.1f), LB.geom, LB.epilogue, stream));
   }
   {
     const Layer& L = m->layers[li++];            // DSen2Net.py:35,38,41
-    HIP_TRY(launch_conv3x3(make_params(a, P + L.w_off, P + L.b_off, skip, out, n, h, w, m->cout, 0.f), L.geom.cin_pad,
-                           L.geom.cout_pad, L.epilogue, stream));
+    HIP_TRY(launch_conv3x3(make_params(a, P + L.w_off, P + L.b_off, skip, out, n, h, w, m->cout, 0.f), L.geom, L.epilogue, stream));
   }
   return DSEN2_OK;
 }
@@ -234,8 +243,7 @@ int dsen2_conv3x3_nhwc(const float* dev_in, const float* host_kernel, const floa
   HIP_TRY(hipMalloc((void**)&dev, staged.size() * sizeof(float)));
   hipError_t e = hipMemcpy(dev, staged.data(), staged.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess)
-    e = launch_conv3x3(make_params(dev_in, dev, dev + wf, dev_aux, dev_out, n, h, w, cout, res_scale), g.cin_pad,
-                       g.cout_pad, epilogue, stream);
+    e = launch_conv3x3(make_params(dev_in, dev, dev + wf, dev_aux, dev_out, n, h, w, cout, res_scale), g, epilogue, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFree(dev);
   if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "conv3x3 launch: %s", hipGetErrorString(e));
@@ -257,9 +265,9 @@ int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, c
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(launch_conv3x3(p, L.geom.cin_pad, L.geom.cout_pad, L.epilogue, stream));   // warm-up
+  HIP_TRY(launch_conv3x3(p, L.geom, L.epilogue, stream));   // warm-up
   HIP_TRY(hipEventRecord(e0, stream));
-  for (int i = 0; i < iters; ++i) HIP_TRY(launch_conv3x3(p, L.geom.cin_pad, L.geom.cout_pad, L.epilogue, stream));
+  for (int i = 0; i < iters; ++i) HIP_TRY(launch_conv3x3(p, L.geom, L.epilogue, stream));
   HIP_TRY(hipEventRecord(e1, stream));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;

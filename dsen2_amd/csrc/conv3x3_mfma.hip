@@ -27,8 +27,9 @@ namespace dsen2 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CIN, int KC, int NT>
+template <int CIN, int KC, int NT, int NWAVES>
 struct ConvCfg {
+  static constexpr int THREADS = 64 * NWAVES;
   static constexpr int NCC = CIN / KC;            // input-channel chunks
   static constexpr int NCHUNK = NCC * 9;          // (chunk, tap) steps
   static constexpr int PSTR = KC + 4;             // floats per halo pixel in LDS
@@ -37,23 +38,25 @@ struct ConvCfg {
   static constexpr int WCH = KC * NT;             // floats per weight chunk
   static constexpr int QPP = KC / 4;              // 16-byte pieces per pixel
   static constexpr int IN_PIECES = kHaloPix * QPP;
-  static constexpr int IN_ROUNDS = (IN_PIECES + kThreads - 1) / kThreads;
+  static constexpr int IN_ROUNDS = (IN_PIECES + THREADS - 1) / THREADS;
   static constexpr int W_PIECES = WCH / 4;
-  static constexpr int W_ROUNDS = (W_PIECES + kThreads - 1) / kThreads;
+  static constexpr int W_ROUNDS = (W_PIECES + THREADS - 1) / THREADS;
   static constexpr int WN = NT >= 64 ? NT / 64 : 1;   // waves along output channels
   static constexpr int MB = NT / (32 * WN);           // 32-channel blocks per wave
-  static constexpr int WP = 8 / WN;                   // waves along pixels
+  static constexpr int WP = NWAVES / WN;              // waves along pixels
   static constexpr int PB = 8 / WP;                   // 32-pixel (2 rows x 16) blocks per wave
   static constexpr size_t LDS_BYTES = (size_t)(NIBUF * IN_FLOATS + 2 * WCH) * sizeof(float);
   static_assert(CIN % KC == 0 && KC % 8 == 0, "channel chunking");
-  static_assert(IN_ROUNDS <= 9, "input chunk prefetch is spread over the 9 taps");
+  static_assert(NWAVES % WN == 0 && 8 % WP == 0, "wave grid");
+  static constexpr int RPT = (IN_ROUNDS + 8) / 9;     // input-prefetch rounds handled per tap
   static_assert((IN_FLOATS * 4) % 16 == 0 && (WCH * 4) % 16 == 0, "16-byte aligned LDS carve");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int CIN, int KC, int COUT, int NT, int EPI>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_mfma_kernel(const ConvParams p) {
-  using C = ConvCfg<CIN, KC, NT>;
+template <int CIN, int KC, int COUT, int NT, int EPI, int NWAVES, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kernel(const ConvParams p) {
+  using C = ConvCfg<CIN, KC, NT, NWAVES>;
+  constexpr int kThreads = C::THREADS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const in_s = smem;                              // [NIBUF][324][PSTR]
   float* const w_s = smem + C::NIBUF * C::IN_FLOATS;     // [2][KC/4][NT][4]
@@ -162,9 +165,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_mfma_kernel(const ConvPar
       // issue next step's global loads first: their latency hides behind this step's MFMAs
       f32x4 wr[C::W_ROUNDS];
       if (more_w) load_w(chunk + 1, wr);
-      f32x4 ir = {0.f, 0.f, 0.f, 0.f};
-      const bool do_in = more_in && tap < C::IN_ROUNDS;
-      if (do_in) ir = load_in(tap < C::IN_ROUNDS ? tap : 0, cc + 1);
+      f32x4 ir[C::RPT];
+#pragma unroll
+      for (int q = 0; q < C::RPT; ++q) {
+        const int r = tap * C::RPT + q;
+        if (r < C::IN_ROUNDS && more_in) ir[q] = load_in(r < C::IN_ROUNDS ? r : 0, cc + 1);
+      }
 
       const int dy = tap / 3, dx = tap - dy * 3;
       const float* const bp = ib + b_lane + (dy * kHalo + dx) * C::PSTR;
@@ -187,7 +193,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_mfma_kernel(const ConvPar
       }
 
       if (more_w) store_w(wb_next, wr);
-      if (do_in) store_in(ib_next, tap < C::IN_ROUNDS ? tap : 0, ir);
+#pragma unroll
+      for (int q = 0; q < C::RPT; ++q) {
+        const int r = tap * C::RPT + q;
+        if (r < C::IN_ROUNDS && more_in) store_in(ib_next, r < C::IN_ROUNDS ? r : 0, ir[q]);
+      }
       __syncthreads();
     }
   }
@@ -234,10 +244,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_mfma_kernel(const ConvPar
   }
 }
 
-template <int CIN, int KC, int COUT, int NT, int EPI>
+template <int CIN, int KC, int COUT, int NT, int EPI, int NWAVES = 8, int WAVES_PER_SIMD = 2>
 static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
-  using C = ConvCfg<CIN, KC, NT>;
-  auto kern = conv3x3_mfma_kernel<CIN, KC, COUT, NT, EPI>;
+  using C = ConvCfg<CIN, KC, NT, NWAVES>;
+  auto kern = conv3x3_mfma_kernel<CIN, KC, COUT, NT, EPI, NWAVES, WAVES_PER_SIMD>;
   static bool attr_set[64] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -251,20 +261,28 @@ static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
   const long long tiles = (long long)p.n * p.tiles_x * p.tiles_y;
   if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)tiles, COUT / NT, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(kThreads), C::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), C::LDS_BYTES, stream, p);
   return hipGetLastError();
 }
+
+int g_body_variant = 4;   // tuning knob (dsen2_set_tuning): structure used for F->F body convs packed from now on
+                          // 4 = persistent pipelined kernel (conv3x3_body.hip); 0 = one tile per workgroup; 1-3 = A/B variants
 
 bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
   if (cin <= 0 || cout <= 0) return false;
   if (epilogue == kEpiSkipNCHW) {
     if (cout > 32 || (cin != 128 && cin != 256)) return false;
-    *g = PackGeom{32, 32, cin, 32};
+    *g = PackGeom{32, 32, cin, 32, 0};
     return true;
   }
   if (cout != 128 && cout != 256) return false;
-  if (cin <= 16) { *g = PackGeom{16, 128, 16, cout}; return true; }
-  if (cin == 128 || cin == 256) { *g = PackGeom{32, 128, cin, cout}; return true; }
+  if (cin <= 16) { *g = PackGeom{16, 128, 16, cout, 0}; return true; }
+  if (cin == 128 && cout == 128) {
+    const int v = g_body_variant;
+    *g = PackGeom{(v == 1 || v == 2 || v == 5) ? 16 : 32, 128, cin, cout, v};
+    return true;
+  }
+  if (cin == 256 && cout == 256) { *g = PackGeom{32, 128, cin, cout, g_body_variant >= 4 ? 4 : 0}; return true; }
   return false;
 }
 
@@ -284,7 +302,25 @@ void pack_conv_weights_host(const float* k, int cin, int cout, const PackGeom& g
             }
 }
 
-hipError_t launch_conv3x3(const ConvParams& p, int cin_pad, int cout_pad, int epilogue, hipStream_t stream) {
+hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, hipStream_t stream) {
+  const int cin_pad = geom.cin_pad, cout_pad = geom.cout_pad;
+  if (geom.variant >= 4 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)
+    return launch_conv3x3_body(p, cin_pad, epilogue, geom.variant, stream);
+  if (cin_pad == 128 && cout_pad == 128 && epilogue != kEpiSkipNCHW && geom.variant != 0) {
+    const bool relu = epilogue == kEpiRelu;
+    switch (geom.variant) {
+      case 1:   // KC=16, 8 waves, 4 waves/SIMD -> 2 workgroups per CU
+        return relu ? launch_one<128, 16, 128, 128, kEpiRelu, 8, 4>(p, stream)
+                    : launch_one<128, 16, 128, 128, kEpiResidual, 8, 4>(p, stream);
+      case 2:   // KC=16, 4 waves (64 ch x 128 px each), 2 workgroups per CU
+        return relu ? launch_one<128, 16, 128, 128, kEpiRelu, 4, 2>(p, stream)
+                    : launch_one<128, 16, 128, 128, kEpiResidual, 4, 2>(p, stream);
+      case 3:   // KC=32, 4 waves, one workgroup per CU, one wave per SIMD
+        return relu ? launch_one<128, 32, 128, 128, kEpiRelu, 4, 1>(p, stream)
+                    : launch_one<128, 32, 128, 128, kEpiResidual, 4, 1>(p, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
 #define DSEN2_CASE(CI, KC_, CO, NT_, EP) \
   if (cin_pad == CI && cout_pad == CO && epilogue == EP) return launch_one<CI, KC_, CO, NT_, EP>(p, stream);
   DSEN2_CASE(16, 16, 128, 128, kEpiRelu)

@@ -23,7 +23,6 @@ namespace dsen2 {
 constexpr int kTile = 16;                 // output pixels per workgroup edge (16 x 16 tile)
 constexpr int kHalo = kTile + 2;          // 18
 constexpr int kHaloPix = kHalo * kHalo;   // 324
-constexpr int kThreads = 512;             // 8 waves: 2 per SIMD
 
 enum Epilogue : int { kEpiRelu = 0, kEpiResidual = 1, kEpiSkipNCHW = 2 };
 
@@ -40,9 +39,13 @@ struct ConvParams {
 };
 
 // Supported (CIN_PAD, COUT_PAD, epilogue) combinations; returns hipErrorInvalidValue otherwise.
-hipError_t launch_conv3x3(const ConvParams& p, int cin_pad, int cout_pad, int epilogue, hipStream_t stream);
+struct PackGeom { int kc, nt, cin_pad, cout_pad, variant; };
+hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, hipStream_t stream);
+extern int g_body_variant;
+extern int g_body_ablate;   // timing-only ablation mask of the persistent body kernel (0 = off)
+// persistent pipelined F->F kernel (conv3x3_body.hip); weights packed with KC=32, NT=128
+hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream);
 // Geometry helpers for packing
-struct PackGeom { int kc, nt, cin_pad, cout_pad; };
 bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g);
 size_t packed_weight_floats(const PackGeom& g);
 // host_kernel HWIO (3,3,cin,cout) -> packed layout (host memory, zero padded)

@@ -39,6 +39,12 @@ const char *dsen2_last_error(void);
 /* Number of visible HIP devices whose gcnArchName starts with "gfx950"; <0 on error. */
 int dsen2_device_count(void);
 
+/* Tuning knobs (no reference counterpart).  key 0 = structure of the 128->128 body convolution used by
+ * models whose weights are loaded AFTER the call (0 = default; other values are experimental variants
+ * kept for A/B measurements, all numerically equivalent up to summation order).  key 1 = timing-only
+ * ablation mask of the persistent body kernel (diagnostics: outputs are wrong while it is non-zero). */
+int dsen2_set_tuning(int key, int value);
+
 /* ---- network object -------------------------------------------------------------------------
  * dsen2_model_create  <->  s2model(input_shape, num_layers, feature_size)   utils/DSen2Net.py:18-43
  *   c10/c20/c60: channel counts of the 10 m / 20 m / 60 m inputs (c60 = 0 for the 2-input net).
