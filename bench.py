@@ -132,10 +132,17 @@ def main():
         ms_res = model.time_body_conv(2, a, r, o, iters=10)              # conv-B (+bias, *0.1, +residual)
         ms = 0.5 * (ms_relu + ms_res)
         flops = pix * FLOP_PER_PIXEL_BODY
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, 'profiles', 'body_conv_traffic.json')
+        if os.path.exists(tj) and args.batch == BATCH:      # PMC counters cannot be read in-process: committed profile
+            tdat = json.load(open(tj))
+            traffic, traffic_src = tdat['traffic_bytes'], tdat['source']
         achieved = flops / (ms * 1e-3) / 1e12
         result['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                              'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                              'kernel': 'conv3x3_mfma_kernel<128,32,128,128> (body 3x3x128x128, fp32 MFMA 32x32x2)',
+                              'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                              'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
+                              'traffic_source': traffic_src,
+                              'kernel': 'conv3x3_body_kernel<128,128,EPI,32,8> (3x3x128x128, fp32 MFMA 32x32x2, persistent)',
                               'ms_per_launch': round(ms, 4), 'ms_relu': round(ms_relu, 4), 'ms_residual': round(ms_res, 4),
                               'flop_per_launch': flops}
         del a, r, o
