@@ -40,6 +40,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU work for cpu_baseline')
     ap.add_argument('--no-gather', action='store_true', help='skip the per-step output all-gather (N>1)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices; '
+                         'the number it prints is not a measurement)')
     args = ap.parse_args()
 
     import torch
@@ -56,11 +59,15 @@ def main():
             sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; launch N>1 with torch.distributed.run\n'
                              % (args.gpus, world))
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank if args.backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        td.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            td.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            td.init_process_group('gloo', rank=rank, world_size=world)
 
     # ---- setup (untimed): weights on rank 0 -> RCCL broadcast; synthetic inputs in HBM ----
     n_params = dweights.num_params(sum(BANDS), BANDS[-1], NUM_LAYERS, FEAT)
@@ -72,13 +79,15 @@ def main():
     xs_np = [(rng.random((args.batch, c, H, W), dtype=np.float32) * np.float32(5.0)) for c in BANDS]
     xs = [torch.from_numpy(a).to(dev) for a in xs_np]
     out = torch.empty((args.batch, BANDS[-1], H, W), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * args.batch, BANDS[-1], H, W), dtype=torch.float32, device=dev) if world > 1 else None
     do_gather = world > 1 and not args.no_gather
+    cdev = dev if args.backend == 'nccl' else torch.device('cpu')          # gloo stages through host memory
+    gathered = torch.empty((world * args.batch, BANDS[-1], H, W), dtype=torch.float32, device=cdev) if do_gather else None
 
     def step():
         model.forward_device(xs, out=out)
         if do_gather:
-            return td.all_gather_into_tensor(gathered, out, async_op=True)
+            # RCCL orders the collective after the forward on the device (it waits on the current stream)
+            return td.all_gather_into_tensor(gathered, out if args.backend == 'nccl' else out.cpu(), async_op=True)
         return None
 
     for _ in range(args.warmup):
@@ -103,7 +112,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -117,7 +126,7 @@ def main():
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'DSen2_20 d=6 F=128 fp32, %d synthetic 32x32 patches (4+6 bands) per GPU per step, '
                                'he_uniform random-init weights' % args.batch,
-                   'batch_per_gpu': args.batch, 'patch': [H, W], 'parallelism': 'patch-sharded dp%d' % world,
+                   'batch_per_gpu': args.batch, 'patch': [H, W], 'parallelism': 'patch-sharded dp%d' % world, 'backend': 'rccl' if args.backend == 'nccl' else 'gloo-rehearsal',
                    'output_gather': bool(do_gather)},
         'net_tflops': round(value * H * W * FLOP_PER_PIXEL_NET / 1e12, 2),
     }

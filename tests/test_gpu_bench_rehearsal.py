@@ -1,0 +1,36 @@
+"""The N>1 control flow of bench.py (weight broadcast, per-step async output gather, barriers, max-over-ranks
+timing, one JSON line from rank 0) rehearsed with 2 ranks on ONE GPU over gloo.  Not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_gloo_rehearsal():
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1', '--batch', '64', '--backend', 'gloo']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                               # exactly one JSON line, from rank 0
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['steps'] == 2 and r['scaling'] == 'weak' and r['config']['output_gather'] is True
+    assert r['value'] > 0 and 'roofline' in r and 'cpu_baseline' not in r
+
+
+def test_bench_single_gpu_line_has_contract_fields():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-budget', '2'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in r, k
+    assert r['dtype'] == 'f32' and r['vs_baseline'] is None and r['roofline']['bound'] == 'mfma'
+    assert 0 < r['roofline']['frac'] <= 1 and r['cpu_baseline']['kind'] == 'port'

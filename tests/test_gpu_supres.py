@@ -101,6 +101,24 @@ def test_predict_surface(model_dir):
     assert do.rmse(out, ref) < 5e-6
 
 
+def test_predict_deep_selects_vdsen2(tmp_path, monkeypatch):
+    """deep=True -> (d, F) = (32, 256) and the s2_033 checkpoint (testing/supres.py:55-57); fp32 on the F=256
+    kernels.  One 16x16 patch keeps the float64 oracle (66 convolutions of 256 channels) to a few seconds."""
+    from dsen2_amd import supres
+    flat = do.he_uniform_weights(10, 6, 32, 256, seed=13, bias_scale=0.02)
+    np.save(str(tmp_path / 's2_033_lr_1e-04.npy'), flat)
+    monkeypatch.setattr(supres, 'MDL_PATH', str(tmp_path) + os.sep)
+    supres.clear_model_cache()
+    xs = do.synthetic_inputs(1, 16, 16, (4, 6), seed=21)
+    out, printed = quiet(supres._predict, xs, ((4, None, None), (6, None, None)), True)
+    assert 's2_033_lr_1e-04.hdf5' in printed
+    ref = c_oracle.forward(xs, flat, 32, 256)
+    err = do.rmse(out, ref)
+    print('VDSen2 fp32 rmse', err)
+    assert err < 2e-5
+    supres.clear_model_cache()
+
+
 def test_image_smaller_than_a_patch_is_rejected(model_dir):
     """The reference indexes with a negative origin and dies on a shape mismatch (patches.py:52,62-72);
     here the same input raises ValueError before any GPU work."""
