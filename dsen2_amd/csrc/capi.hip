@@ -65,6 +65,11 @@ int dsen2_set_tuning(int key, int value) {
     g_body_variant = value;
     return DSEN2_OK;
   }
+  if (key == 2) {   // output-layer kernel: 1 = 16x16x4 (default), 0 = padded 32-wide block
+    if (value != 0 && value != 1) return fail(DSEN2_ERR_INVALID, "output variant %d unknown", value);
+    g_out_variant = value;
+    return DSEN2_OK;
+  }
   if (key == 1) {   // timing-only ablation of the persistent body kernel (wrong results when non-zero)
     g_body_ablate = value;
     return DSEN2_OK;

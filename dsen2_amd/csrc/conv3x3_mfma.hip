@@ -265,6 +265,7 @@ static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+int g_out_variant = 1;    // 1 = 16x16x4 output-layer kernel (conv3x3_out.hip); 0 = padded 32-wide block of this file
 int g_body_variant = 4;   // tuning knob (dsen2_set_tuning): structure used for F->F body convs packed from now on
                           // 4 = persistent pipelined kernel (conv3x3_body.hip); 0 = one tile per workgroup; 1-3 = A/B variants
 
@@ -272,6 +273,7 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
   if (cin <= 0 || cout <= 0) return false;
   if (epilogue == kEpiSkipNCHW) {
     if (cout > 32 || (cin != 128 && cin != 256)) return false;
+    if (cout <= 16 && g_out_variant == 1) { *g = PackGeom{32, 16, cin, 16, 7}; return true; }   // conv3x3_out.hip
     *g = PackGeom{32, 32, cin, 32, 0};
     return true;
   }
@@ -304,6 +306,7 @@ void pack_conv_weights_host(const float* k, int cin, int cout, const PackGeom& g
 
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, hipStream_t stream) {
   const int cin_pad = geom.cin_pad, cout_pad = geom.cout_pad;
+  if (geom.variant == 7 && epilogue == kEpiSkipNCHW) return launch_conv3x3_out(p, cin_pad, stream);
   if (geom.variant >= 4 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)
     return launch_conv3x3_body(p, cin_pad, epilogue, geom.variant, stream);
   if (cin_pad == 128 && cout_pad == 128 && epilogue != kEpiSkipNCHW && geom.variant != 0) {
