@@ -22,13 +22,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH = 512
 H = W = 32
-BANDS = (4, 6)
-NUM_LAYERS, FEAT = 6, 128
-FLOP_PER_PIXEL_BODY = 2 * 9 * FEAT * FEAT                       # one 3x3x128x128 conv: 294 912 FLOP / px
-FLOP_PER_PIXEL_NET = 2 * 9 * (sum(BANDS) * FEAT + 2 * NUM_LAYERS * FEAT * FEAT + FEAT * BANDS[-1])
-PEAK_F32_MFMA_TFLOPS = 157.3                                    # MI355X_MICROARCH.md: Peak FP32 (matrix)
+# BASELINE.json configs.  The default (what the driver runs) is configs[1]; the others are for our own runs.
+CONFIGS = {
+    'dsen2_20_fp32': dict(metric='32x32x6 patches/sec (DSen2_20, d=6, batch 512)', bands=(4, 6), d=6, f=128,
+                          batch=512, precision='fp32', dtype='f32', peak=157.3,
+                          workload='DSen2_20 d=6 F=128 fp32'),
+    'dsen2_60_fp32': dict(metric='32x32x2 patches/sec (DSen2_60, d=6, batch 512)', bands=(4, 6, 2), d=6, f=128,
+                          batch=512, precision='fp32', dtype='f32', peak=157.3,
+                          workload='DSen2_60 d=6 F=128 fp32 (12-band input, 2-band output)'),
+    'vdsen2_20_fp32': dict(metric='32x32x6 patches/sec (VDSen2_20, d=32, F=256, batch 256, fp32)', bands=(4, 6), d=32,
+                           f=256, batch=256, precision='fp32', dtype='f32', peak=157.3,
+                           workload='VDSen2_20 d=32 F=256 fp32'),
+    'vdsen2_20_bf16': dict(metric='32x32x6 patches/sec (VDSen2_20, d=32, F=256, batch 256, bf16)', bands=(4, 6), d=32,
+                           f=256, batch=256, precision='bf16', dtype='bf16', peak=2500.0,
+                           workload='VDSen2_20 d=32 F=256, bf16 operands / fp32 accumulate + residual stream'),
+}
+# peaks: MI355X_MICROARCH.md — FP32 matrix 157.3 TFLOP/s, BF16 MFMA ~2.5 PFLOP/s dense
 
 
 def main():
@@ -36,7 +46,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=BATCH, help=argparse.SUPPRESS)
+    ap.add_argument('--config', default='dsen2_20_fp32', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU work for cpu_baseline')
     ap.add_argument('--no-gather', action='store_true', help='skip the per-step output all-gather (N>1)')
@@ -44,6 +55,15 @@ def main():
                     help='gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices; '
                          'the number it prints is not a measurement)')
     args = ap.parse_args()
+
+    cfg = CONFIGS[args.config]
+    BANDS, NUM_LAYERS, FEAT = cfg['bands'], cfg['d'], cfg['f']
+    BATCH = cfg['batch']
+    if args.batch <= 0:
+        args.batch = BATCH
+    FLOP_PER_PIXEL_BODY = 2 * 9 * FEAT * FEAT                    # one 3x3xFxF conv (294 912 FLOP/px at F=128)
+    FLOP_PER_PIXEL_NET = 2 * 9 * (sum(BANDS) * FEAT + 2 * NUM_LAYERS * FEAT * FEAT + FEAT * BANDS[-1])
+    PEAK = cfg['peak']
 
     import torch
     import torch.distributed as td
@@ -73,7 +93,8 @@ def main():
     n_params = dweights.num_params(sum(BANDS), BANDS[-1], NUM_LAYERS, FEAT)
     flat = dweights.random_he_uniform(sum(BANDS), BANDS[-1], NUM_LAYERS, FEAT, seed=1) if rank == 0 else None
     flat = ddist.broadcast_weights(flat, n_params, device=dev)
-    model = s2model(tuple((b, None, None) for b in BANDS), num_layers=NUM_LAYERS, feature_size=FEAT, device=dev)
+    model = s2model(tuple((b, None, None) for b in BANDS), num_layers=NUM_LAYERS, feature_size=FEAT, device=dev,
+                    precision=cfg['precision'])
     model.set_weights_flat(flat)
     rng = np.random.Generator(np.random.PCG64(rank))             # U[0,1)*5, PCG64(seed)
     xs_np = [(rng.random((args.batch, c, H, W), dtype=np.float32) * np.float32(5.0)) for c in BANDS]
@@ -120,12 +141,12 @@ def main():
     value = world * args.batch * args.steps / elapsed
 
     result = {
-        'metric': '32x32x6 patches/sec (DSen2_20, d=6, batch 512)',
+        'metric': cfg['metric'],
         'value': round(value, 1), 'unit': 'patches/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'DSen2_20 d=6 F=128 fp32, %d synthetic 32x32 patches (4+6 bands) per GPU per step, '
-                               'he_uniform random-init weights' % args.batch,
+        'dtype': cfg['dtype'], 'data': 'synthetic',
+        'config': {'workload': '%s, %d synthetic 32x32 patches (%s bands) per GPU per step, he_uniform random-init '
+                               'weights' % (cfg['workload'], args.batch, '+'.join(str(b) for b in BANDS)),
                    'batch_per_gpu': args.batch, 'patch': [H, W], 'parallelism': 'patch-sharded dp%d' % world, 'backend': 'rccl' if args.backend == 'nccl' else 'gloo-rehearsal',
                    'output_gather': bool(do_gather)},
         'net_tflops': round(value * H * W * FLOP_PER_PIXEL_NET / 1e12, 2),
@@ -134,29 +155,35 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: the 3x3x128x128 body convolution (98.97 % of FLOPs) ----
         pix = args.batch * H * W
+        bf = cfg['precision'] == 'bf16'
         a = torch.randn((args.batch, H, W, FEAT), dtype=torch.float32, device=dev)
         r = torch.randn((args.batch, H, W, FEAT), dtype=torch.float32, device=dev)
-        o = torch.empty_like(a)
+        if bf:
+            a = a.to(torch.bfloat16)
+            o = torch.empty((args.batch * 3 // 2 + 1, H, W, FEAT), dtype=torch.float32, device=dev)   # fp32 out + bf16 copy
+        else:
+            o = torch.empty_like(a)
         ms_relu = model.time_body_conv(1, a, None, o, iters=10)          # conv-A (+bias+ReLU)
         ms_res = model.time_body_conv(2, a, r, o, iters=10)              # conv-B (+bias, *0.1, +residual)
         ms = 0.5 * (ms_relu + ms_res)
         flops = pix * FLOP_PER_PIXEL_BODY
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, 'profiles', 'body_conv_traffic.json')
-        if os.path.exists(tj) and args.batch == BATCH:      # PMC counters cannot be read in-process: committed profile
-            tdat = json.load(open(tj))
+        if os.path.exists(tj) and args.config == 'dsen2_20_fp32' and args.batch == BATCH:
+            tdat = json.load(open(tj))      # PMC counters cannot be read in-process: committed profile of this config
             traffic, traffic_src = tdat['traffic_bytes'], tdat['source']
         achieved = flops / (ms * 1e-3) / 1e12
-        result['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                              'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+        result['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK,
+                              'unit': 'TFLOP/s', 'frac': round(achieved / PEAK, 4), 'traffic': traffic,
                               'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
                               'traffic_source': traffic_src,
-                              'kernel': 'conv3x3_body_kernel<128,128,EPI,32,8> (3x3x128x128, fp32 MFMA 32x32x2, persistent)',
+                              'kernel': 'conv3x3_body_kernel (3x3x%dx%d, %s, persistent)' % (
+                                  FEAT, FEAT, 'bf16 MFMA 32x32x16' if bf else 'fp32 MFMA 32x32x2'),
                               'ms_per_launch': round(ms, 4), 'ms_relu': round(ms_relu, 4), 'ms_residual': round(ms_res, 4),
                               'flop_per_launch': flops}
         del a, r, o
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'dsen2_20_fp32':
         # ---- CPU baseline: the same graph on the host cores, bounded sample (oracle/ = checker code) ----
         from oracle import cpu_graph
         pps, sample, cores, y_cpu = cpu_graph.time_patches_per_s(flat, xs_np, NUM_LAYERS, FEAT, budget_s=args.cpu_budget)

@@ -28,7 +28,7 @@ def _stream_ptr(device):
 class S2Model(object):
     """What keras' Model is to the reference: built by s2model(), then load_weights() and predict()."""
 
-    def __init__(self, input_shape, num_layers, feature_size, device=None):
+    def __init__(self, input_shape, num_layers, feature_size, device=None, precision='fp32'):
         if len(input_shape) not in (2, 3):
             raise ValueError('input_shape must describe 2 or 3 inputs, got %r' % (input_shape,))
         if not torch.cuda.is_available():
@@ -42,8 +42,11 @@ class S2Model(object):
         self._handle = ctypes.c_void_p(0)
         c60 = self.bands[2] if len(self.bands) == 3 else 0
         with torch.cuda.device(self.device):
+            if precision not in ('fp32', 'bf16'):
+                raise ValueError("precision must be 'fp32' or 'bf16'")
+            self.precision = precision
             _lib.call('dsen2_model_create', ctypes.byref(self._handle), self.bands[0], self.bands[1], c60,
-                      self.num_layers, self.feature_size, 0)
+                      self.num_layers, self.feature_size, 1 if precision == 'bf16' else 0)
         self._workspace = None
         self.max_workspace_bytes = 6 << 30   # predict() sizes its internal batches to stay below this
 
@@ -135,9 +138,29 @@ class S2Model(object):
             pass
 
 
-def s2model(input_shape, num_layers=32, feature_size=256, device=None):
-    """utils/DSen2Net.py:18 — same positional arguments and defaults."""
-    return S2Model(input_shape, num_layers, feature_size, device=device)
+def s2model(input_shape, num_layers=32, feature_size=256, device=None, precision='fp32'):
+    """utils/DSen2Net.py:18 — same positional arguments and defaults.  precision='bf16' runs the residual-block
+    convolutions on the bf16 matrix cores (fp32 accumulate, fp32 residual stream)."""
+    return S2Model(input_shape, num_layers, feature_size, device=device, precision=precision)
+
+
+def conv3x3_body_bf16(x_bf16, kernel_hwio, bias, epilogue=0, aux=None, res_scale=RES_SCALE):
+    """Kernel-level entry point of the bf16 body convolution: x_bf16 NHWC torch.bfloat16 CUDA tensor.
+    Returns bf16 NHWC (epilogue 0) or (fp32 NHWC, bf16 NHWC copy) (epilogue 1)."""
+    n, h, w, feat = x_bf16.shape
+    kernel_hwio = np.ascontiguousarray(kernel_hwio, np.float32)
+    bias = np.ascontiguousarray(bias, np.float32)
+    if epilogue == 0:
+        out = torch.empty((n, h, w, feat), dtype=torch.bfloat16, device=x_bf16.device)
+        out2 = None
+    else:
+        out = torch.empty((n, h, w, feat), dtype=torch.float32, device=x_bf16.device)
+        out2 = torch.empty((n, h, w, feat), dtype=torch.bfloat16, device=x_bf16.device)
+    with torch.cuda.device(x_bf16.device):
+        _lib.call('dsen2_conv3x3_body_bf16', _ptr(x_bf16), kernel_hwio.ctypes.data_as(_lib.c_float_p),
+                  bias.ctypes.data_as(_lib.c_float_p), _ptr(aux), _ptr(out), _ptr(out2), n, h, w, feat, int(epilogue),
+                  float(res_scale), _stream_ptr(x_bf16.device))
+    return out if epilogue == 0 else (out, out2)
 
 
 def conv3x3_nhwc(x, kernel_hwio, bias, epilogue=0, aux=None, res_scale=RES_SCALE):

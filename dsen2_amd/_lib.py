@@ -33,6 +33,8 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_void_p]),
     'dsen2_conv3x3_nhwc': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_int, c_int, ctypes.c_float, c_void_p]),
+    'dsen2_conv3x3_body_bf16': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_int, c_int, ctypes.c_float, c_void_p]),
     'dsen2_model_time_body_conv': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_void_p, c_float_p]),
     'dsen2_upsample_mirror_bilinear': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float,

@@ -34,6 +34,7 @@ int fail(int code, const char* fmt, ...) {
 struct Layer {
   int cin, cout;        // real channel counts (keras)
   int epilogue;
+  bool bf16;            // weights packed as bf16 for the bf16-operand body kernel
   PackGeom geom;
   size_t w_off, b_off;  // float offsets inside dev_params
   size_t flat_off;      // float offset of the kernel inside the keras-flat array
@@ -99,7 +100,7 @@ int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_lay
   if (c10 <= 0 || c20 <= 0 || c60 < 0 || num_layers < 0) return fail(DSEN2_ERR_INVALID, "bad channel/layer counts");
   if (feature_size != 128 && feature_size != 256)
     return fail(DSEN2_ERR_INVALID, "feature_size %d unsupported (128 or 256)", feature_size);
-  if (precision != 0) return fail(DSEN2_ERR_INVALID, "precision %d not built (0 = fp32)", precision);
+  if (precision != 0 && precision != 1) return fail(DSEN2_ERR_INVALID, "precision %d unknown (0 = fp32, 1 = bf16)", precision);
   const int cin = c10 + c20 + c60;
   const int cout = c60 > 0 ? c60 : c20;   // utils/DSen2Net.py:35 — input_shape[-1][0]
   if (cin > 16) return fail(DSEN2_ERR_INVALID, "%d input channels > 16", cin);
@@ -132,7 +133,8 @@ int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_lay
     }
     L.flat_off = flat;
     flat += (size_t)9 * L.cin * L.cout + L.cout;
-    L.w_off = dev; dev += align_up(packed_weight_floats(L.geom));
+    L.bf16 = precision == 1 && L.cin == feature_size && L.cout == feature_size;   // residual-block convolutions only
+    L.w_off = dev; dev += align_up(L.bf16 ? (size_t)9 * L.cin * L.cout / 2 : packed_weight_floats(L.geom));
     L.b_off = dev; dev += align_up((size_t)L.geom.cout_pad);
     m->layers.push_back(L);
   }
@@ -158,7 +160,10 @@ int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t coun
   for (const Layer& L : m->layers) {
     const float* k = host_flat + L.flat_off;
     const float* b = k + (size_t)9 * L.cin * L.cout;
-    pack_conv_weights_host(k, L.cin, L.cout, L.geom, staged.data() + L.w_off);
+    if (L.bf16)
+      pack_conv_weights_bf16_host(k, L.cin, L.cout, reinterpret_cast<uint16_t*>(staged.data() + L.w_off));
+    else
+      pack_conv_weights_host(k, L.cin, L.cout, L.geom, staged.data() + L.w_off);
     memcpy(staged.data() + L.b_off, b, sizeof(float) * L.cout);
   }
   if (!m->dev_params) HIP_TRY(hipMalloc((void**)&m->dev_params, m->dev_param_floats * sizeof(float)));
@@ -170,7 +175,9 @@ int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t coun
 int dsen2_model_workspace_bytes(const dsen2_model* m, int n, int h, int w, size_t* bytes) {
   if (!m || !bytes || n <= 0 || h <= 0 || w <= 0) return fail(DSEN2_ERR_INVALID, "bad argument");
   const size_t pix = (size_t)n * h * w;
-  *bytes = (align_up(pix * 16) + 2 * align_up(pix * m->feat)) * sizeof(float);
+  // fp32: x0 | a | t.   bf16: x0 | a (fp32) | abf, tbf (bf16, half an fp32 tensor each)
+  const size_t full = align_up(pix * m->feat), halves = 2 * align_up(pix * m->feat / 2);
+  *bytes = (align_up(pix * 16) + full + (full > halves ? full : halves)) * sizeof(float);
   return DSEN2_OK;
 }
 
@@ -184,7 +191,7 @@ static int check_shape(const dsen2_model* m, int n, int h, int w) {
 static ConvParams make_params(const float* in, const float* wpk, const float* bias, const float* aux, float* out,
                               int n, int h, int w, int cout_real, float scale) {
   ConvParams p;
-  p.in = in; p.wpk = wpk; p.bias = bias; p.aux = aux; p.out = out;
+  p.in = in; p.wpk = wpk; p.bias = bias; p.aux = aux; p.out = out; p.out2 = nullptr;
   p.n = n; p.h = h; p.w = w;
   p.tiles_x = (w + kTile - 1) / kTile; p.tiles_y = (h + kTile - 1) / kTile;
   p.cout_real = cout_real; p.res_scale = scale;
@@ -215,6 +222,23 @@ int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, cons
     const Layer& L = m->layers[li++];            // DSen2Net.py:29
     HIP_TRY(launch_conv3x3(make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f), L.geom, L.epilogue, stream));
   }
+  if (m->precision == 1) {
+    // bf16 operands / fp32 accumulate and residual stream: `a` stays fp32, `t` and the operand copy `abf` of
+    // `a` are bf16 (each half the size of an fp32 activation, together they fit the fp32 path's `t`)
+    void* abf = t;
+    void* tbf = reinterpret_cast<char*>(t) + align_up(pix * m->feat / 2) * sizeof(float);
+    HIP_TRY(launch_f32_to_bf16(a, abf, pix * m->feat, stream));
+    for (int i = 0; i < m->num_layers; ++i) {
+      const Layer& LA = m->layers[li++];
+      ConvParams pa = make_params(reinterpret_cast<const float*>(abf), P + LA.w_off, P + LA.b_off, nullptr,
+                                  reinterpret_cast<float*>(tbf), n, h, w, 0, 0.f);
+      HIP_TRY(launch_conv3x3_body_bf16(pa, m->feat, kEpiRelu, stream));
+      const Layer& LB = m->layers[li++];
+      ConvParams pb = make_params(reinterpret_cast<const float*>(tbf), P + LB.w_off, P + LB.b_off, a, a, n, h, w, 0, 0.1f);
+      pb.out2 = abf;
+      HIP_TRY(launch_conv3x3_body_bf16(pb, m->feat, kEpiResidual, stream));
+    }
+  } else
   for (int i = 0; i < m->num_layers; ++i) {      // DSen2Net.py:31-32 -> :9-15
     const Layer& LA = m->layers[li++];
     HIP_TRY(launch_conv3x3(make_params(a, P + LA.w_off, P + LA.b_off, nullptr, t, n, h, w, 0, 0.f), LA.geom, LA.epilogue, stream));
@@ -255,6 +279,36 @@ int dsen2_conv3x3_nhwc(const float* dev_in, const float* host_kernel, const floa
   return DSEN2_OK;
 }
 
+int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, const float* host_bias,
+                            const float* dev_aux, void* dev_out, void* dev_out2_bf16, int n, int h, int w, int feat,
+                            int epilogue, float res_scale, void* stream_) {
+  if (!dev_in_bf16 || !host_kernel || !host_bias || !dev_out) return fail(DSEN2_ERR_INVALID, "NULL argument");
+  if (feat != 128 && feat != 256) return fail(DSEN2_ERR_INVALID, "feat %d unsupported", feat);
+  if (epilogue == kEpiResidual && (!dev_aux || !dev_out2_bf16)) return fail(DSEN2_ERR_INVALID, "residual needs aux and out2");
+  if (epilogue != kEpiRelu && epilogue != kEpiResidual) return fail(DSEN2_ERR_INVALID, "epilogue %d", epilogue);
+  int rc = check_shape(nullptr, n, h, w);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t wn = (size_t)9 * feat * feat;
+  std::vector<uint16_t> wb(wn);
+  pack_conv_weights_bf16_host(host_kernel, feat, feat, wb.data());
+  char* dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev, wn * 2 + feat * sizeof(float)));
+  hipError_t e = hipMemcpy(dev, wb.data(), wn * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dev + wn * 2, host_bias, feat * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    ConvParams p = make_params(reinterpret_cast<const float*>(dev_in_bf16), reinterpret_cast<const float*>(dev),
+                               reinterpret_cast<const float*>(dev + wn * 2), dev_aux, reinterpret_cast<float*>(dev_out),
+                               n, h, w, 0, res_scale);
+    p.out2 = dev_out2_bf16;
+    e = launch_conv3x3_body_bf16(p, feat, epilogue, stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "bf16 conv launch: %s", hipGetErrorString(e));
+  return DSEN2_OK;
+}
+
 int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, const float* dev_aux, float* dev_out,
                                int n, int h, int w, int iters, void* stream_, float* ms_per_launch) {
   if (!m || !dev_in || !dev_out || !ms_per_launch || iters <= 0) return fail(DSEN2_ERR_INVALID, "bad argument");
@@ -266,13 +320,19 @@ int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, c
   if (L.epilogue == kEpiResidual && !dev_aux) return fail(DSEN2_ERR_INVALID, "residual layer needs dev_aux");
   hipStream_t stream = (hipStream_t)stream_;
   const float* P = m->dev_params;
-  const ConvParams p = make_params(dev_in, P + L.w_off, P + L.b_off, dev_aux, dev_out, n, h, w, 0, 0.1f);
+  ConvParams p = make_params(dev_in, P + L.w_off, P + L.b_off, dev_aux, dev_out, n, h, w, 0, 0.1f);
+  // bf16 model: dev_in is bf16 NHWC; kEpiRelu writes bf16 to dev_out; kEpiResidual writes fp32 to dev_out and its
+  // bf16 copy right behind it (dev_out must then hold 1.5 fp32 tensors)
+  if (L.bf16 && L.epilogue == kEpiResidual) p.out2 = dev_out + (size_t)n * h * w * m->feat;
+  auto launch = [&]() -> hipError_t {
+    return L.bf16 ? launch_conv3x3_body_bf16(p, m->feat, L.epilogue, stream) : launch_conv3x3(p, L.geom, L.epilogue, stream);
+  };
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(launch_conv3x3(p, L.geom, L.epilogue, stream));   // warm-up
+  HIP_TRY(launch());   // warm-up
   HIP_TRY(hipEventRecord(e0, stream));
-  for (int i = 0; i < iters; ++i) HIP_TRY(launch_conv3x3(p, L.geom, L.epilogue, stream));
+  for (int i = 0; i < iters; ++i) HIP_TRY(launch());
   HIP_TRY(hipEventRecord(e1, stream));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;

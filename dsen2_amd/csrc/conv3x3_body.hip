@@ -21,6 +21,7 @@ namespace dsen2 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // (A global_load_lds weight stream was tried and dropped: with a DMA in flight hipcc turns every counted
 //  lgkmcnt(N) of the fragment pipeline into lgkmcnt(0), which costs more than the ds_writes it saves.)
@@ -53,7 +54,14 @@ struct BodyCfg {
 
 // ABL: timing-only ablation mask (results are WRONG when non-zero; tools/ablate_body_conv.py):
 //   1 = no output stores, 2 = no residual loads, 4 = no weight stream, 8 = no input stream, 16 = no barriers
-template <int CIN, int COUT, int EPI, int KC, int NWAVES, int ABL = 0, bool LT = false>
+//
+// BF16 = true: the same kernel byte for byte on the memory side — an LDS/global "word" then holds two bf16
+// channels, so CIN counts 32-bit WORDS per input pixel (= channels / 2), a 16-byte piece is 8 channels, a step is
+// (tap, 64 channels) — and v_mfma_f32_32x32x16_bf16 takes a whole 16-byte fragment per instruction (lane l holds
+// k = 8*(l>>5) .. +7, exactly the 8 consecutive channels one ds_read_b128 returns).  fp32 accumulate; kEpiRelu
+// writes bf16; kEpiResidual keeps the residual stream in fp32 (aux/out) and also writes its bf16 copy (out2),
+// which is what the next block's first convolution reads.
+template <int CIN, int COUT, int EPI, int KC, int NWAVES, int ABL = 0, bool LT = false, bool BF16 = false>
 __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const ConvParams p, const int n_items) {
   using B = BodyCfg<KC, NWAVES>;
   constexpr int NT = B::NT, THREADS = B::THREADS, PSTR = B::PSTR, IN_FLOATS = B::IN_FLOATS, WCH = B::WCH;
@@ -207,20 +215,29 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
     // for the item) + a UNIFORM per-register part (SGPR soffset), so the 64 residual loads and 64 stores of a
     // lane need no per-access address registers; elements outside a ragged tile get an out-of-range lane
     // offset instead of a branch (loads return 0, stores are dropped).
+    constexpr bool kOutBf16 = BF16 && EPI == kEpiRelu;          // element type of p.out
+    constexpr unsigned OB = kOutBf16 ? 2u : 4u;
     const unsigned img_bytes = (unsigned)(img_pix * COUT * sizeof(float));
     const auto aux_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.aux) + (EPI == kEpiResidual ? (size_t)img * img_pix * COUT : 0), 0,
         EPI == kEpiResidual ? img_bytes : 0, 0x00020000);
-    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)img * img_pix * COUT, 0, img_bytes, 0x00020000);
-    // (pixel row 0 of this wave's strip, column 4*hsel, channel ch0); register r of block pb adds epi_soff(pb, r)
-    const unsigned lane_voff = (unsigned)(((ty0 + RS * wp) * p.w + tx0 + 4 * hsel) * COUT + ch0) * 4u;
-    auto epi_soff = [&](int mb, int pb, int r) -> int {    // pixel (r&3) + 8*(r>>2) (+ 4*hsel in lane_voff) of a 2x16 block
-      return (((2 * pb + (r >> 3)) * p.w + (r & 3) + 8 * ((r >> 2) & 1)) * COUT + mb * 32) * 4;
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.out) + (size_t)img * img_pix * COUT * OB, 0, (unsigned)(img_pix * COUT * OB), 0x00020000);
+    const auto out2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.out2) + (BF16 && EPI == kEpiResidual ? (size_t)img * img_pix * COUT * 2 : 0), 0,
+        BF16 && EPI == kEpiResidual ? (unsigned)(img_pix * COUT * 2) : 0, 0x00020000);
+    // (pixel row 0 of this wave's strip, column 4*hsel, channel ch0) in ELEMENTS; register r of block pb adds
+    // the uniform epi_eoff(mb, pb, r); byte offsets = elements * element size
+    const unsigned lane_eoff = (unsigned)(((ty0 + RS * wp) * p.w + tx0 + 4 * hsel) * COUT + ch0);
+    const unsigned lane_voff = lane_eoff * 4u;
+    auto epi_eoff = [&](int mb, int pb, int r) -> int {    // pixel (r&3) + 8*(r>>2) (+ 4*hsel in lane_eoff) of a 2x16 block
+      return ((2 * pb + (r >> 3)) * p.w + (r & 3) + 8 * ((r >> 2) & 1)) * COUT + mb * 32;
     };
-    auto epi_voff = [&](int pb, int r) -> unsigned {
-      const bool ok = full_tile || (ty0 + RS * wp + 2 * pb + (r >> 3) < p.h && tx0 + 4 * hsel + (r & 3) + 8 * ((r >> 2) & 1) < p.w);
-      return ok ? lane_voff : 0x80000000u;
+    auto epi_soff = [&](int mb, int pb, int r) -> int { return epi_eoff(mb, pb, r) * 4; };
+    auto epi_ok = [&](int pb, int r) -> bool {
+      return full_tile || (ty0 + RS * wp + 2 * pb + (r >> 3) < p.h && tx0 + 4 * hsel + (r & 3) + 8 * ((r >> 2) & 1) < p.w);
     };
+    auto epi_voff = [&](int pb, int r) -> unsigned { return epi_ok(pb, r) ? lane_voff : 0x80000000u; };
 
     f32x16 acc[2][PB];
 #pragma unroll
@@ -296,12 +313,18 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
           // reads next to their first use and the wave stalls on LDS latency every other k-step)
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < (BF16 ? 1 : 4); ++j)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-              for (int pb = 0; pb < PB; ++pb)
-                acc[mb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_cur[pb][j], w_cur[mb][j], acc[mb][pb], 0, 0, 0);
+              for (int pb = 0; pb < PB; ++pb) {
+                if constexpr (BF16)
+                  acc[mb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x_cur[pb]),
+                                                                        __builtin_bit_cast(bf16x8, w_cur[mb]),
+                                                                        acc[mb][pb], 0, 0, 0);
+                else
+                  acc[mb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_cur[pb][j], w_cur[mb][j], acc[mb][pb], 0, 0, 0);
+              }
 #pragma unroll
           for (int q = 0; q < 2; ++q) w_cur[q] = w_nxt[q];
 #pragma unroll
@@ -336,8 +359,18 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
             v = res + v * p.res_scale;                       // -ffp-contract=off: two roundings, as keras
           }
           if constexpr (!(ABL & 1)) {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, epi_voff(pb, r),
-                                                  epi_soff(mb, pb, r), 0);
+            if constexpr (kOutBf16) {
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), out_rsrc,
+                                                    epi_ok(pb, r) ? lane_eoff * 2u : 0x80000000u,
+                                                    epi_eoff(mb, pb, r) * 2, 0);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, epi_voff(pb, r),
+                                                    epi_soff(mb, pb, r), 0);
+              if constexpr (BF16)      // bf16 copy of the new residual stream for the next block's conv-A
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), out2_rsrc,
+                                                      epi_ok(pb, r) ? lane_eoff * 2u : 0x80000000u,
+                                                      epi_eoff(mb, pb, r) * 2, 0);
+            }
           } else {
             asm volatile("" ::"v"(v));                       // keep the accumulators live without storing
           }
@@ -349,10 +382,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
 
 int g_body_ablate = 0;
 
-template <int CIN, int COUT, int EPI, int KC = 32, int NWAVES = 8, int ABL = 0, bool LT = false>
+template <int CIN, int COUT, int EPI, int KC = 32, int NWAVES = 8, int ABL = 0, bool LT = false, bool BF16 = false>
 static hipError_t launch_body_one(const ConvParams& p, hipStream_t stream) {
   using B = BodyCfg<KC, NWAVES>;
-  auto kern = conv3x3_body_kernel<CIN, COUT, EPI, KC, NWAVES, ABL, LT>;
+  auto kern = conv3x3_body_kernel<CIN, COUT, EPI, KC, NWAVES, ABL, LT, BF16>;
   static bool attr_set[64] = {};
   static int cus[64] = {};
   int dev = 0;
@@ -397,6 +430,16 @@ hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int 
   if (feat == 128 && epilogue == kEpiResidual) return launch_body_one<128, 128, kEpiResidual>(p, stream);
   if (feat == 256 && epilogue == kEpiRelu) return launch_body_one<256, 256, kEpiRelu>(p, stream);
   if (feat == 256 && epilogue == kEpiResidual) return launch_body_one<256, 256, kEpiResidual>(p, stream);
+  return hipErrorInvalidValue;
+}
+
+// bf16 operands, fp32 accumulate: F -> F with F = 128 or 256 (CIN template argument = F/2 words per pixel)
+hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, hipStream_t stream) {
+  if (epilogue == kEpiResidual && !p.out2) return hipErrorInvalidValue;
+  if (feat == 256 && epilogue == kEpiRelu) return launch_body_one<128, 256, kEpiRelu, 32, 8, 0, false, true>(p, stream);
+  if (feat == 256 && epilogue == kEpiResidual) return launch_body_one<128, 256, kEpiResidual, 32, 8, 0, false, true>(p, stream);
+  if (feat == 128 && epilogue == kEpiRelu) return launch_body_one<64, 128, kEpiRelu, 32, 8, 0, false, true>(p, stream);
+  if (feat == 128 && epilogue == kEpiResidual) return launch_body_one<64, 128, kEpiResidual, 32, 8, 0, false, true>(p, stream);
   return hipErrorInvalidValue;
 }
 

@@ -20,6 +20,8 @@
 //     'same' convolution is materialised in LDS by predicated loads, never branched per MFMA.
 //   * one s_barrier per (tap, chunk) step = per 64 MFMAs of each wave; next step's global loads are issued
 //     before the MFMAs of the current one and land in LDS after them.
+#include <string.h>
+
 #include "dsen2_internal.h"
 
 namespace dsen2 {
@@ -301,6 +303,29 @@ void pack_conv_weights_host(const float* k, int cin, int cout, const PackGeom& g
             for (int j = 0; j < 4; ++j, ++i) {
               const int c = cc * g.kc + 4 * gg + j, oc = slab * g.nt + o;
               dst[i] = (c < cin && oc < cout) ? k[((size_t)tap * cin + c) * cout + oc] : 0.f;
+            }
+}
+
+static inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+void pack_conv_weights_bf16_host(const float* k, int cin, int cout, uint16_t* dst) {
+  // [slab][cc (64 channels)][tap][g (8 channels)][o (128)][j (8)]: one (slab, cc, tap) chunk = 16 KiB, the LDS image
+  const int ncc = cin / 64, nslab = cout / 128;
+  size_t i = 0;
+  for (int slab = 0; slab < nslab; ++slab)
+    for (int cc = 0; cc < ncc; ++cc)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int g = 0; g < 8; ++g)
+          for (int o = 0; o < 128; ++o)
+            for (int j = 0; j < 8; ++j, ++i) {
+              const int c = cc * 64 + 8 * g + j, oc = slab * 128 + o;
+              dst[i] = f32_to_bf16_rne(k[((size_t)tap * cin + c) * cout + oc]);
             }
 }
 

@@ -31,7 +31,8 @@ struct ConvParams {
   const float* wpk;    // packed weights (layout above)
   const float* bias;   // [COUT_PAD]
   const float* aux;    // kEpiResidual: NHWC [n][h][w][COUT]; kEpiSkipNCHW: NCHW [n][cout_real][h][w]
-  float* out;          // NHWC [n][h][w][COUT] or NCHW [n][cout_real][h][w]
+  float* out;          // NHWC [n][h][w][COUT] or NCHW [n][cout_real][h][w]  (bf16 body kernel, kEpiRelu: bf16 NHWC)
+  void* out2;          // bf16 body kernel, kEpiResidual: bf16 NHWC copy of `out`; otherwise unused
   int n, h, w;
   int tiles_x, tiles_y;
   int cout_real;       // kEpiSkipNCHW only
@@ -46,6 +47,11 @@ extern int g_out_variant;
 // last layer, F -> Cout<=16, 16x16x4 MFMA (conv3x3_out.hip); weights packed with KC=32, NT=16
 hipError_t launch_conv3x3_out(const ConvParams& p, int feat, hipStream_t stream);
 extern int g_body_ablate;   // timing-only ablation mask of the persistent body kernel (0 = off)
+// bf16-operand form of the persistent kernel: in bf16 NHWC, weights packed by pack_conv_weights_bf16_host
+hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, hipStream_t stream);
+// kernel HWIO fp32 -> bf16 packed [slab][cc(64 ch)][tap][g(8 groups of 8 ch)][o(128)][8]; dst holds 9*cin*cout uint16
+void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, uint16_t* dst);
+hipError_t launch_f32_to_bf16(const float* in, void* out_bf16, size_t count, hipStream_t stream);
 // persistent pipelined F->F kernel (conv3x3_body.hip); weights packed with KC=32, NT=128
 hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream);
 // Geometry helpers for packing

@@ -50,7 +50,8 @@ int dsen2_set_tuning(int key, int value);
  *   c10/c20/c60: channel counts of the 10 m / 20 m / 60 m inputs (c60 = 0 for the 2-input net).
  *   The output has the channel count of the last input and that input is added back (:35-41).
  *   feature_size must be a multiple of 128 (reference uses 128 and 256, testing/supres.py:56,59).
- *   precision: 0 = fp32 everywhere (exact-f32 MFMA); 1 = bf16 operands, fp32 accumulate/residual.
+ *   precision: 0 = fp32 everywhere (exact-f32 MFMA); 1 = bf16 operands for the residual-block convolutions
+ *   (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 residual stream, fp32 first and last convolution.
  */
 int dsen2_model_create(dsen2_model **out, int c10, int c20, int c60, int num_layers, int feature_size,
                        int precision);
@@ -86,6 +87,16 @@ int dsen2_model_forward(dsen2_model *m, const float *dev_x10, const float *dev_x
 int dsen2_conv3x3_nhwc(const float *dev_in, const float *host_kernel, const float *host_bias,
                        const float *dev_aux, float *dev_out, int n, int h, int w, int cin, int cout,
                        int epilogue, float res_scale, void *stream);
+
+/* bf16-operand form of one residual-block convolution (feat -> feat, feat = 128 or 256): dev_in_bf16 is NHWC
+ * bf16; the fp32 HWIO kernel is rounded to bf16 (RNE) while packing; accumulation is fp32.
+ *   epilogue 0: dev_out (bf16 NHWC)  = relu(conv + bias)
+ *   epilogue 1: dev_out (fp32 NHWC)  = dev_aux (fp32 NHWC) + res_scale * (conv + bias), and dev_out2_bf16 = its
+ *               bf16 copy (what the next block's first convolution reads)
+ * Test path (packs on every call, synchronises). */
+int dsen2_conv3x3_body_bf16(const void *dev_in_bf16, const float *host_kernel, const float *host_bias,
+                            const float *dev_aux, void *dev_out, void *dev_out2_bf16, int n, int h, int w, int feat,
+                            int epilogue, float res_scale, void *stream);
 
 /* Body-convolution micro-benchmark hook: runs `iters` launches of the 128->128 (or F->F) kernel on
  * caller-provided NHWC buffers with already-packed weights held by `m` (layer index `layer`, 1-based
