@@ -7,9 +7,9 @@ N>1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 one rank per GPU over RCCL.  A step = one forward pass of 512 patches per rank (weak scaling: patches
-are independent units, no collective inside the network); the all-gather of the step's outputs
-("gather of outputs over xGMI") is issued asynchronously after each step and completed inside the
-timed region.  Rank 0 prints ONE JSON line.
+are independent units, no collective inside the network); the gather of each step's outputs to rank 0
+("gather of outputs over xGMI") is issued asynchronously, overlaps the next step's forward, and is
+completed inside the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -99,34 +99,46 @@ def main():
     rng = np.random.Generator(np.random.PCG64(rank))             # U[0,1)*5, PCG64(seed)
     xs_np = [(rng.random((args.batch, c, H, W), dtype=np.float32) * np.float32(5.0)) for c in BANDS]
     xs = [torch.from_numpy(a).to(dev) for a in xs_np]
-    out = torch.empty((args.batch, BANDS[-1], H, W), dtype=torch.float32, device=dev)
     do_gather = world > 1 and not args.no_gather
     cdev = dev if args.backend == 'nccl' else torch.device('cpu')          # gloo stages through host memory
-    gathered = torch.empty((world * args.batch, BANDS[-1], H, W), dtype=torch.float32, device=cdev) if do_gather else None
+    # two output buffers: the gather of step i (RCCL stream) overlaps the forward of step i+1 (compute stream)
+    outs = [torch.empty((args.batch, BANDS[-1], H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+    out = outs[0]
+    gather_list = None
+    if do_gather and rank == 0:
+        gather_list = [[torch.empty((args.batch, BANDS[-1], H, W), dtype=torch.float32, device=cdev) for _ in range(world)]
+                       for _ in range(2)]
+    pending = [None, None]
 
-    def step():
-        model.forward_device(xs, out=out)
+    def step(i):
+        """forward of 512 patches into outs[i%2]; then start gathering it to rank 0 (7 peers x 12.6 MB, one xGMI
+        link each) without waiting: the handle is waited on before outs[i%2] is written again, two steps later."""
+        b = i & 1
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        model.forward_device(xs, out=outs[b])
         if do_gather:
-            # RCCL orders the collective after the forward on the device (it waits on the current stream)
-            return td.all_gather_into_tensor(gathered, out if args.backend == 'nccl' else out.cpu(), async_op=True)
-        return None
+            src = outs[b] if args.backend == 'nccl' else outs[b].cpu()
+            pending[b] = td.gather(src, gather_list[b] if rank == 0 else None, dst=0, async_op=True)
 
-    for _ in range(args.warmup):
-        h = step()
-        if h is not None:
-            h.wait()
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pending = None
-    for _ in range(args.steps):
-        if pending is not None:
-            pending.wait()                                       # previous step's gather must have read `out`
-        pending = step()
-    if pending is not None:
-        pending.wait()
+    for i in range(args.steps):
+        step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         td.barrier()
@@ -136,6 +148,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
+    out = outs[(args.steps - 1) & 1]
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
