@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdsen2_hip.so')
+LIB_PATH = os.environ.get('DSEN2_HIP_LIB') or os.path.join(_HERE, 'libdsen2_hip.so')   # override: A/B of experimental builds
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_WEIGHTS, ERR_WORKSPACE, ERR_NO_DEVICE = -1, -2, -3, -4, -5

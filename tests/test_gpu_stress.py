@@ -1,0 +1,32 @@
+"""Race / hazard screen of the persistent body convolution (the kernel with hand-ordered pipelines): many
+launches on fresh random data at 1..8 items per workgroup, every output element compared with the simple
+one-tile-per-workgroup structure, plus bitwise run-to-run determinism.  (guide: "screen a sync-structure edit for
+races over many runs at several sizes")."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_body_conv_matches_reference_structure_over_many_runs():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stress_body_conv.py')], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert 'total mismatching elements = 0' in p.stdout
+
+
+def test_forward_is_bitwise_reproducible_across_launches():
+    from dsen2_amd import weights as W
+    from dsen2_amd.DSen2Net import s2model
+    for prec in ('fp32', 'bf16'):
+        m = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128, precision=prec)
+        m.set_weights_flat(W.random_he_uniform(10, 6, 6, 128, seed=5, bias_scale=0.05))
+        xs = [torch.rand((300, 4, 32, 32), device='cuda') * 5, torch.rand((300, 6, 32, 32), device='cuda') * 5]
+        ref = m.forward_device(xs).clone()
+        for _ in range(8):
+            assert torch.equal(m.forward_device(xs), ref), prec

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Race / hazard screen for the body convolution: many launches on random data, every output element compared
+with the one-tile-per-workgroup reference structure (variant 0), several batch sizes (1..8 items per workgroup)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dsen2_amd import _lib, weights as W          # noqa: E402
+from dsen2_amd.DSen2Net import s2model            # noqa: E402
+
+flat = W.random_he_uniform(10, 6, 6, 128, seed=1, bias_scale=0.05)
+models = {}
+for v in (0, 4):
+    _lib.call('dsen2_set_tuning', 0, v)
+    models[v] = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128)
+    models[v].set_weights_flat(flat)
+_lib.call('dsen2_set_tuning', 0, 4)
+bad_total = 0
+for B in (3, 64, 65, 200, 512):
+    for rep in range(6):
+        a = torch.randn((B, 32, 32, 128), device='cuda'); r = torch.randn((B, 32, 32, 128), device='cuda')
+        for layer in (1, 2):
+            o0 = torch.empty_like(a); o4 = torch.empty_like(a)
+            models[0].time_body_conv(layer, a, r if layer == 2 else None, o0, iters=1)
+            models[4].time_body_conv(layer, a, r if layer == 2 else None, o4, iters=1)
+            nbad = int(((o4 - o0).abs() > 1e-4).sum())
+            bad_total += nbad
+            if nbad:
+                print('MISMATCH B=%d rep=%d layer=%d: %d elements' % (B, rep, layer, nbad))
+print('stress: total mismatching elements = %d' % bad_total)
+sys.exit(1 if bad_total else 0)
