@@ -133,3 +133,24 @@ def test_missing_checkpoint_raises_oserror(tmp_path, monkeypatch):
     supres.clear_model_cache()
     with pytest.raises(OSError):
         quiet(supres.DSen2_20, np.zeros((240, 240, 4), np.float32), np.zeros((120, 120, 6), np.float32))
+
+
+def test_cli_npz_round_trip(model_dir, tmp_path, golden_dir):
+    """python -m dsen2_amd.cli: the super-resolution + npz-writer part of s2_tiles_supres.py (:332-342,:383-420)."""
+    from dsen2_amd import cli, supres
+    g = np.load(os.path.join(golden_dir, 'tile_T33UUB_crop.npz'))
+    inp = str(tmp_path / 'tile.npz')
+    np.savez(inp, data10=g['d10'], data20=g['d20'], data60=g['d60'])
+    out = str(tmp_path / 'sr.npz')
+    rc, printed = quiet(cli.main, [inp, out, '--run_60', '--copy_original_bands', '--models', supres.MDL_PATH])
+    assert rc == 0 and 'Super-resolving the 60m data into 10m bands' in printed
+    bands = np.load(out, allow_pickle=True)['bands'].item()
+    assert list(bands) == ['B4', 'B3', 'B2', 'B8', 'SRB5', 'SRB6', 'SRB7', 'SRB8A', 'SRB11', 'SRB12', 'SRB1', 'SRB9']
+    assert all(b.shape == (264, 264) for b in bands.values())
+    ref20, _ = quiet(supres.DSen2_20, g['d10'], g['d20'])
+    assert np.array_equal(bands['SRB5'], ref20[:, :, 0])
+    # ROI rounded to 60 m pixel boundaries (s2_tiles_supres.py:131-134)
+    out2 = str(tmp_path / 'roi.npz')
+    quiet(cli.main, [inp, out2, '--roi_x_y', '5,7,250,245', '--models', supres.MDL_PATH])
+    b2 = np.load(out2, allow_pickle=True)['bands'].item()
+    assert b2['SRB5'].shape == (240, 246)
