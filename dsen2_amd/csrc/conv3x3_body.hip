@@ -26,6 +26,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // (A global_load_lds weight stream was tried and dropped: with a DMA in flight hipcc turns every counted
 //  lgkmcnt(N) of the fragment pipeline into lgkmcnt(0), which costs more than the ds_writes it saves.)
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {     // DPP quad_perm lane exchange (hazards padded by hipcc)
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// 4x4 transpose across the 4 lanes of a quad: in (lane i, register j) -> out (lane j, register i).
+// Turns the MFMA result "lane = channel, register = pixel" into "lane = pixel, registers = 4 consecutive
+// channels", i.e. 16 contiguous bytes of an NHWC pixel per lane.  16 VALU ops, no LDS.
+__device__ __forceinline__ void quad_transpose(float& a0, float& a1, float& a2, float& a3, bool odd, bool hi) {
+  float s_, r_;
+  s_ = odd ? a0 : a1; r_ = quad_perm<0xB1>(s_); a0 = odd ? r_ : a0; a1 = odd ? a1 : r_;     // lanes i <-> i^1
+  s_ = odd ? a2 : a3; r_ = quad_perm<0xB1>(s_); a2 = odd ? r_ : a2; a3 = odd ? a3 : r_;
+  s_ = hi ? a0 : a2; r_ = quad_perm<0x4E>(s_); a0 = hi ? r_ : a0; a2 = hi ? a2 : r_;        // lanes i <-> i^2
+  s_ = hi ? a1 : a3; r_ = quad_perm<0x4E>(s_); a1 = hi ? r_ : a1; a3 = hi ? a3 : r_;
+}
+
 // KC = input channels per step, NWAVES = waves per workgroup:
 //   <32, 8>: one workgroup per CU, wave tile 64 ch x 64 px      <16, 4>: two workgroups per CU, 64 ch x 128 px
 template <int KC_, int NWAVES_>
@@ -210,13 +228,17 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
     const int tyi = trem / p.tiles_x;
     const int ty0 = tyi * kTile, tx0 = (trem - tyi * p.tiles_x) * kTile;
     const bool full_tile = ty0 + kTile <= p.h && tx0 + kTile <= p.w;
-    const int ch0 = slab * NT + wn * 64 + l31;
-    // Epilogue addressing through buffer descriptors (one per image): byte offset = lane part (VGPR, fixed
-    // for the item) + a UNIFORM per-register part (SGPR soffset), so the 64 residual loads and 64 stores of a
-    // lane need no per-access address registers; elements outside a ragged tile get an out-of-range lane
-    // offset instead of a branch (loads return 0, stores are dropped).
+    // Epilogue geometry.  The MFMA result has lane = output channel (l31), register r = pixel
+    // (r&3) + 8*(r>>2) + 4*hsel of a 2x16 block.  A 4x4 transpose inside each lane quad turns register quad
+    // g = r>>2 into "lane = pixel (l&3) + 8*(g&1) + 4*hsel of row g>>1, 4 registers = channels 4*(l31>>2) .. +3":
+    // 16 contiguous bytes of NHWC per lane, 8 full 128-byte lines per wave instruction, 16 instead of 64 memory
+    // instructions per lane.  Addressing through buffer descriptors (one per image): byte offset = lane part
+    // (VGPR, fixed for the item) + a UNIFORM per-(mb, pb, g) part (SGPR soffset); elements outside a ragged
+    // tile get an out-of-range lane offset instead of a branch (loads return 0, stores are dropped).
     constexpr bool kOutBf16 = BF16 && EPI == kEpiRelu;          // element type of p.out
     constexpr unsigned OB = kOutBf16 ? 2u : 4u;
+    const int chq = slab * NT + wn * 64 + 4 * (l31 >> 2);       // first of this lane's 4 channels (block mb adds 32)
+    const bool q_odd = lane & 1, q_hi = lane & 2;
     const unsigned img_bytes = (unsigned)(img_pix * COUT * sizeof(float));
     const auto aux_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.aux) + (EPI == kEpiResidual ? (size_t)img * img_pix * COUT : 0), 0,
@@ -226,18 +248,23 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
     const auto out2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(p.out2) + (BF16 && EPI == kEpiResidual ? (size_t)img * img_pix * COUT * 2 : 0), 0,
         BF16 && EPI == kEpiResidual ? (unsigned)(img_pix * COUT * 2) : 0, 0x00020000);
-    // (pixel row 0 of this wave's strip, column 4*hsel, channel ch0) in ELEMENTS; register r of block pb adds
-    // the uniform epi_eoff(mb, pb, r); byte offsets = elements * element size
-    const unsigned lane_eoff = (unsigned)(((ty0 + RS * wp) * p.w + tx0 + 4 * hsel) * COUT + ch0);
-    const unsigned lane_voff = lane_eoff * 4u;
-    auto epi_eoff = [&](int mb, int pb, int r) -> int {    // pixel (r&3) + 8*(r>>2) (+ 4*hsel in lane_eoff) of a 2x16 block
+    // element offset of (row 0 of this wave's strip, column (l&3) + 4*hsel, channel chq); (mb, pb, g) adds epi_eoff
+    const int ex = tx0 + (lane & 3) + 4 * hsel, ey = ty0 + RS * wp;
+    const unsigned lane_eoff = (unsigned)((ey * p.w + ex) * COUT + chq);
+    auto epi_eoff = [&](int mb, int pb, int g) -> int { return ((2 * pb + (g >> 1)) * p.w + 8 * (g & 1)) * COUT + mb * 32; };
+    auto epi_ok = [&](int pb, int g) -> bool {
+      return full_tile || (ey + 2 * pb + (g >> 1) < p.h && ex + 8 * (g & 1) < p.w);
+    };
+    // kEpiRelu keeps the un-transposed form (lane = channel l31, register r = pixel (r&3) + 8*(r>>2) + 4*hsel: two
+    // full 128-byte lines per dword store instruction): with nothing to load, the 256 VALU ops of the transposes
+    // cost more than the 48 memory instructions they save (measured: conv-A 1.09 -> 1.11 ms fp32, 0.29 -> 0.33 bf16).
+    const unsigned lane_eoff1 = (unsigned)((ey * p.w + tx0 + 4 * hsel) * COUT + slab * NT + wn * 64 + l31);
+    auto epi_eoff1 = [&](int mb, int pb, int r) -> int {
       return ((2 * pb + (r >> 3)) * p.w + (r & 3) + 8 * ((r >> 2) & 1)) * COUT + mb * 32;
     };
-    auto epi_soff = [&](int mb, int pb, int r) -> int { return epi_eoff(mb, pb, r) * 4; };
-    auto epi_ok = [&](int pb, int r) -> bool {
-      return full_tile || (ty0 + RS * wp + 2 * pb + (r >> 3) < p.h && tx0 + 4 * hsel + (r & 3) + 8 * ((r >> 2) & 1) < p.w);
+    auto epi_ok1 = [&](int pb, int r) -> bool {
+      return full_tile || (ey + 2 * pb + (r >> 3) < p.h && tx0 + 4 * hsel + (r & 3) + 8 * ((r >> 2) & 1) < p.w);
     };
-    auto epi_voff = [&](int pb, int r) -> unsigned { return epi_ok(pb, r) ? lane_voff : 0x80000000u; };
 
     f32x16 acc[2][PB];
 #pragma unroll
@@ -246,7 +273,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
       for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mb][pb][e] = 0.f;
-    float resv[2][kPrefetchRes ? PB : 1][16];   // residual tile, fetched under the last step's MFMAs
+    f32x4 resv[2][kPrefetchRes ? PB : 1][4];    // residual tile (16 B per register quad), fetched under the last step's MFMAs
 
 #pragma unroll 1
     for (int cc = 0; cc < NCC; ++cc) {
@@ -304,9 +331,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
 #pragma unroll
                 for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-                  for (int r = 0; r < 16; ++r)
-                    resv[mb][pb][r] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(aux_rsrc, epi_voff(pb, r), epi_soff(mb, pb, r), 0));
+                  for (int g = 0; g < 4; ++g)
+                    resv[mb][pb][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        aux_rsrc, epi_ok(pb, g) ? lane_eoff * 4u : 0x80000000u, epi_eoff(mb, pb, g) * 4, 0));
             }
           }
           // pin the order: everything above is issued ahead of this k-step's MFMAs (hipcc otherwise sinks the
@@ -337,46 +364,86 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
     }
 
     // ---- epilogue of this item (its stores retire behind the next item's MFMAs) ----
+    if constexpr (EPI == kEpiRelu) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float bias1 = p.bias[slab * NT + wn * 64 + l31 + mb * 32];
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = fmaxf(acc[mb][pb][r] + bias1, 0.f);
+            if constexpr (!(ABL & 1)) {
+              if constexpr (kOutBf16)
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), out_rsrc,
+                                                      epi_ok1(pb, r) ? lane_eoff1 * 2u : 0x80000000u,
+                                                      epi_eoff1(mb, pb, r) * 2, 0);
+              else
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc,
+                                                      epi_ok1(pb, r) ? lane_eoff1 * 4u : 0x80000000u,
+                                                      epi_eoff1(mb, pb, r) * 4, 0);
+            } else {
+              asm volatile("" ::"v"(v));                       // keep the accumulators live without storing
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-      const float bias = p.bias[ch0 + mb * 32];
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + chq + mb * 32);
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[mb][pb][r] + bias;
+        for (int g = 0; g < 4; ++g) {
+          float a0 = acc[mb][pb][4 * g], a1 = acc[mb][pb][4 * g + 1], a2 = acc[mb][pb][4 * g + 2], a3 = acc[mb][pb][4 * g + 3];
+          quad_transpose(a0, a1, a2, a3, q_odd, q_hi);
+          f32x4 v = {a0 + bias[0], a1 + bias[1], a2 + bias[2], a3 + bias[3]};
           if constexpr (EPI == kEpiRelu) {
-            v = fmaxf(v, 0.f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           } else {
-            float res = 1.f;
+            f32x4 rr = {1.f, 1.f, 1.f, 1.f};
             if constexpr (!(ABL & 2)) {
               if constexpr (kPrefetchRes)
-                res = resv[mb][pb][r];
+                rr = resv[mb][pb][g];
               else   // two workgroups per CU: the other one's MFMAs cover this latency
-                res = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(aux_rsrc, epi_voff(pb, r),
-                                                                                    epi_soff(mb, pb, r), 0));
+                rr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   aux_rsrc, epi_ok(pb, g) ? lane_eoff * 4u : 0x80000000u,
+                                                   epi_eoff(mb, pb, g) * 4, 0));
             }
-            v = res + v * p.res_scale;                       // -ffp-contract=off: two roundings, as keras
+            v = rr + v * p.res_scale;       // -ffp-contract=off: two roundings, as keras
           }
+          const unsigned vo = epi_ok(pb, g) ? lane_eoff : 0x20000000u;      // elements; OOB once scaled to bytes
           if constexpr (!(ABL & 1)) {
             if constexpr (kOutBf16) {
-              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), out_rsrc,
-                                                    epi_ok(pb, r) ? lane_eoff * 2u : 0x80000000u,
-                                                    epi_eoff(mb, pb, r) * 2, 0);
+              const u32x2 h = {(unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) |
+                                   ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16),
+                               (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) |
+                                   ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16)};
+              __builtin_amdgcn_raw_buffer_store_b64(h, out_rsrc, vo * 2u, epi_eoff(mb, pb, g) * 2, 0);
             } else {
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, epi_voff(pb, r),
-                                                    epi_soff(mb, pb, r), 0);
-              if constexpr (BF16)      // bf16 copy of the new residual stream for the next block's conv-A
-                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), out2_rsrc,
-                                                      epi_ok(pb, r) ? lane_eoff * 2u : 0x80000000u,
-                                                      epi_eoff(mb, pb, r) * 2, 0);
+              // soffset must NOT be a register here: gfx950 reads the 128-bit store data late (the last quad of
+              // each 16-lane row last), and hipcc (ROCm 7.2) only pads the "store data overwritten too early"
+              // hazard when soffset is an immediate — with an SGPR soffset the next VALU write of v's first
+              // register (e.g. the next item's accumulator init) corrupted lanes 12-15 / 28-31 on some schedules.
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc,
+                                                     vo * 4u + (unsigned)(epi_eoff(mb, pb, g) * 4), 0, 0);
+              if constexpr (BF16) {    // bf16 copy of the new residual stream for the next block's conv-A
+                const u32x2 h = {(unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) |
+                                     ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16),
+                                 (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) |
+                                     ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16)};
+                __builtin_amdgcn_raw_buffer_store_b64(h, out2_rsrc, vo * 2u, epi_eoff(mb, pb, g) * 2, 0);
+              }
             }
           } else {
-            asm volatile("" ::"v"(v));                       // keep the accumulators live without storing
+            asm volatile("" ::"v"(v));                         // keep the accumulators live without storing
           }
         }
       }
     }
+    }   // transposed (residual) epilogue
   }
 }
 
