@@ -83,35 +83,54 @@ __device__ __forceinline__ int mirror_index(int i, int dim) {
   return i;
 }
 
+// One thread per group of 4 consecutive output columns of one output row: the row taps are computed once, the
+// four results leave as one 16-byte store when the row length allows it.
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                       size_t total, int h, int w, int oh, int ow, float sy,
-                                                       float oy, float sx, float ox, float post_div) {
-  const size_t oplane = (size_t)oh * ow;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t p = i / oplane;
-    const int rem = (int)(i - p * oplane);
-    const int oi = rem / ow, oj = rem - oi * ow;
+                                                       size_t total_groups, int h, int w, int oh, int ow, int gpr,
+                                                       float sy, float oy, float sx, float ox, float post_div) {
+  const size_t grp_plane = (size_t)oh * gpr;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_groups; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / grp_plane;
+    const int rem = (int)(i - p * grp_plane);
+    const int oi = rem / gpr, oj0 = (rem - oi * gpr) * 4;
     const float r = __fadd_rn(__fmul_rn(sy, (float)oi), oy);
-    const float c = __fadd_rn(__fmul_rn(sx, (float)oj), ox);
-    const float rf = floorf(r), cf = floorf(c);
+    const float rf = floorf(r);
     const int r0 = mirror_index((int)rf, h), r1 = mirror_index((int)ceilf(r), h);
-    const int c0 = mirror_index((int)cf, w), c1 = mirror_index((int)ceilf(c), w);
-    const double dr = (double)__fsub_rn(r, rf), dc = (double)__fsub_rn(c, cf);
-    const float* src = in + p * (size_t)h * w;
-    const double tl = (double)__fdiv_rn(src[r0 * w + c0], 30000.0f), tr = (double)__fdiv_rn(src[r0 * w + c1], 30000.0f);
-    const double bl = (double)__fdiv_rn(src[r1 * w + c0], 30000.0f), br = (double)__fdiv_rn(src[r1 * w + c1], 30000.0f);
-    const double top = (1.0 - dc) * tl + dc * tr;
-    const double bot = (1.0 - dc) * bl + dc * br;
-    const float v = __fmul_rn((float)((1.0 - dr) * top + dr * bot), 30000.0f);
-    out[i] = post_div == 1.0f ? v : __fdiv_rn(v, post_div);   // folds `p20 /= SCALE` (testing/supres.py:24)
+    const double dr = (double)__fsub_rn(r, rf);
+    const float* src0 = in + p * (size_t)h * w + (size_t)r0 * w;
+    const float* src1 = in + p * (size_t)h * w + (size_t)r1 * w;
+    float res[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int oj = oj0 + e < ow ? oj0 + e : ow - 1;
+      const float c = __fadd_rn(__fmul_rn(sx, (float)oj), ox);
+      const float cf = floorf(c);
+      const int c0 = mirror_index((int)cf, w), c1 = mirror_index((int)ceilf(c), w);
+      const double dc = (double)__fsub_rn(c, cf);
+      const double tl = (double)__fdiv_rn(src0[c0], 30000.0f), tr = (double)__fdiv_rn(src0[c1], 30000.0f);
+      const double bl = (double)__fdiv_rn(src1[c0], 30000.0f), br = (double)__fdiv_rn(src1[c1], 30000.0f);
+      const double top = (1.0 - dc) * tl + dc * tr;
+      const double bot = (1.0 - dc) * bl + dc * br;
+      const float v = __fmul_rn((float)((1.0 - dr) * top + dr * bot), 30000.0f);
+      res[e] = post_div == 1.0f ? v : __fdiv_rn(v, post_div);   // folds `p20 /= SCALE` (testing/supres.py:24)
+    }
+    float* dst = out + (p * oh + oi) * (size_t)ow + oj0;
+    if ((ow & 3) == 0) {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{res[0], res[1], res[2], res[3]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (oj0 + e < ow) dst[e] = res[e];
+    }
   }
 }
 
 hipError_t launch_upsample(const float* in, float* out, int planes, int h, int w, int oh, int ow, float post_div,
                            hipStream_t stream) {
-  const size_t total = (size_t)planes * oh * ow;
+  const int gpr = (ow + 3) / 4;                       // 4-column groups per output row
+  const size_t total = (size_t)planes * oh * gpr;
   const double fy = (double)h / oh, fx = (double)w / ow;
-  hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, in, out, total, h, w, oh, ow,
+  hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, in, out, total, h, w, oh, ow, gpr,
                      (float)fy, (float)(0.5 * fy - 0.5), (float)fx, (float)(0.5 * fx - 0.5), post_div);
   return hipGetLastError();
 }
@@ -124,9 +143,33 @@ __device__ __forceinline__ int symmetric_index(int q, int n) {   // q = index in
   return q;
 }
 
-__global__ __launch_bounds__(256) void tile_gather_kernel(const float* __restrict__ img, int H, int W, int C,
-                                                          int border, const int* __restrict__ origins, size_t total,
-                                                          int P, float divisor, float* __restrict__ patches) {
+// One thread per output PIXEL: it reads the pixel's C interleaved source values once (contiguous 4*C bytes) and
+// writes them to the C output planes; each plane's stores are coalesced across the threads of a row.
+template <int C>
+__global__ __launch_bounds__(256) void tile_gather_kernel(const float* __restrict__ img, int H, int W, int border,
+                                                          const int* __restrict__ origins, size_t total_pix, int P,
+                                                          float divisor, float* __restrict__ patches) {
+  const size_t pp = (size_t)P * P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_pix; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t k = i / pp;
+    const int r2 = (int)(i - k * pp);
+    const int y = r2 / P, x = r2 - y * P;
+    const int yy = symmetric_index(origins[2 * k] + y - border, H);
+    const int xx = symmetric_index(origins[2 * k + 1] + x - border, W);
+    const float* src = img + ((size_t)yy * W + xx) * C;
+    float* dst = patches + k * pp * C + r2;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float v = src[c];
+      dst[(size_t)c * pp] = divisor == 1.0f ? v : __fdiv_rn(v, divisor);   // folds `p10 /= SCALE` (supres.py:23)
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tile_gather_generic_kernel(const float* __restrict__ img, int H, int W, int C,
+                                                                  int border, const int* __restrict__ origins,
+                                                                  size_t total, int P, float divisor,
+                                                                  float* __restrict__ patches) {
   const size_t pp = (size_t)P * P, per_patch = pp * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t k = i / per_patch;
@@ -136,35 +179,52 @@ __global__ __launch_bounds__(256) void tile_gather_kernel(const float* __restric
     const int yy = symmetric_index(origins[2 * k] + y - border, H);
     const int xx = symmetric_index(origins[2 * k + 1] + x - border, W);
     const float v = img[((size_t)yy * W + xx) * C + c];
-    patches[i] = divisor == 1.0f ? v : __fdiv_rn(v, divisor);   // folds `p10 /= SCALE` (testing/supres.py:23)
+    patches[i] = divisor == 1.0f ? v : __fdiv_rn(v, divisor);
   }
 }
 
 hipError_t launch_tile_gather(const float* img, int H, int W, int C, int border, const int* origins, int count,
                               int P, float divisor, float* patches, hipStream_t stream) {
-  const size_t total = (size_t)count * C * P * P;
-  if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(tile_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, img, H, W, C, border,
-                     origins, total, P, divisor, patches);
+  const size_t total_pix = (size_t)count * P * P;
+  if (total_pix == 0) return hipSuccess;
+  const dim3 grid(grid_for(total_pix, 256)), block(256);
+  switch (C) {      // the Sentinel-2 band groups: 4 (10 m), 6 (20 m), 2 (60 m)
+    case 2: hipLaunchKernelGGL(tile_gather_kernel<2>, grid, block, 0, stream, img, H, W, border, origins, total_pix, P, divisor, patches); break;
+    case 4: hipLaunchKernelGGL(tile_gather_kernel<4>, grid, block, 0, stream, img, H, W, border, origins, total_pix, P, divisor, patches); break;
+    case 6: hipLaunchKernelGGL(tile_gather_kernel<6>, grid, block, 0, stream, img, H, W, border, origins, total_pix, P, divisor, patches); break;
+    default:
+      hipLaunchKernelGGL(tile_gather_generic_kernel, dim3(grid_for(total_pix * C, 256)), block, 0, stream, img, H, W, C,
+                         border, origins, total_pix * C, P, divisor, patches);
+  }
   return hipGetLastError();
 }
 
 // ---- recomposition (recompose_images, utils/patches.py:374-405) --------------------------------
-__global__ __launch_bounds__(256) void recompose_kernel(const float* __restrict__ patches, int C, int P, int border,
+// One thread per output PIXEL: C coalesced plane reads (neighbouring threads = neighbouring x of the same patch
+// row), one contiguous 4*C-byte HWC write.
+template <int C>
+__global__ __launch_bounds__(256) void recompose_kernel(const float* __restrict__ patches, int P, int border,
                                                         float* __restrict__ img, int H, int W, int x_tiles,
-                                                        int y_tiles, float scale, size_t total) {
+                                                        int y_tiles, float scale, size_t total_pix, int c_rt) {
   const int inner = P - 2 * border;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t pix = i / C;
-    const int c = (int)(i - pix * C);
-    const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+  const int cc = C > 0 ? C : c_rt;
+  const size_t pp = (size_t)P * P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_pix; i += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
     // the LAST tile covering (y, x) wins, as in the reference's sequential overwrite
     const int ty = (y >= H - inner) ? y_tiles - 1 : y / inner;
     const int tx = (x >= W - inner) ? x_tiles - 1 : x / inner;
     const int ys = (ty == y_tiles - 1) ? H - inner : ty * inner;
     const int xs = (tx == x_tiles - 1) ? W - inner : tx * inner;
     const size_t k = (size_t)ty * x_tiles + tx;
-    img[i] = patches[((k * C + c) * P + (border + y - ys)) * P + (border + x - xs)] * scale;
+    const float* src = patches + k * cc * pp + (size_t)(border + y - ys) * P + (border + x - xs);
+    float* dst = img + i * cc;
+    if constexpr (C > 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) dst[c] = src[(size_t)c * pp] * scale;
+    } else {
+      for (int c = 0; c < cc; ++c) dst[c] = src[(size_t)c * pp] * scale;
+    }
   }
 }
 
@@ -174,9 +234,13 @@ hipError_t launch_recompose(const float* patches, int count, int C, int P, int b
   if (inner <= 0 || H < inner || W < inner) return hipErrorInvalidValue;
   const int x_tiles = (W + inner - 1) / inner, y_tiles = (H + inner - 1) / inner;
   if ((long long)x_tiles * y_tiles > count) return hipErrorInvalidValue;
-  const size_t total = (size_t)H * W * C;
-  hipLaunchKernelGGL(recompose_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, patches, C, P, border, img, H,
-                     W, x_tiles, y_tiles, scale, total);
+  const size_t total_pix = (size_t)H * W;
+  const dim3 grid(grid_for(total_pix, 256)), block(256);
+  switch (C) {
+    case 2: hipLaunchKernelGGL(recompose_kernel<2>, grid, block, 0, stream, patches, P, border, img, H, W, x_tiles, y_tiles, scale, total_pix, C); break;
+    case 6: hipLaunchKernelGGL(recompose_kernel<6>, grid, block, 0, stream, patches, P, border, img, H, W, x_tiles, y_tiles, scale, total_pix, C); break;
+    default: hipLaunchKernelGGL(recompose_kernel<0>, grid, block, 0, stream, patches, P, border, img, H, W, x_tiles, y_tiles, scale, total_pix, C);
+  }
   return hipGetLastError();
 }
 

@@ -100,7 +100,9 @@ def gather_patches_device(img_dev, origins_lr, scale, border, patch, n_alloc, di
         first, count, n_out = 0, used, n_alloc
     else:
         n_out = count
-    out = torch.zeros((n_out, C, patch, patch), dtype=torch.float32, device=img_dev.device)
+    out = torch.empty((n_out, C, patch, patch), dtype=torch.float32, device=img_dev.device)
+    if n_out > count:
+        out[count:].zero_()          # the reference's trailing never-filled patches (patches.py:35)
     if count > 0:
         org = torch.from_numpy(np.ascontiguousarray(origins_lr[first:first + count] * scale, dtype=np.int32))
         org = org.to(img_dev.device)
