@@ -35,6 +35,7 @@ struct Layer {
   int cin, cout;        // real channel counts (keras)
   int epilogue;
   bool bf16;            // weights packed as bf16 for the bf16-operand body kernel
+  int bf16_variant;     // structure of that kernel the weights were packed for
   PackGeom geom;
   size_t w_off, b_off;  // float offsets inside dev_params
   size_t flat_off;      // float offset of the kernel inside the keras-flat array
@@ -64,6 +65,16 @@ int dsen2_set_tuning(int key, int value) {
   if (key == 0) {
     if (value < 0 || value > 6) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
     g_body_variant = value;
+    return DSEN2_OK;
+  }
+  if (key == 4) {   // bf16 body kernel structure (F = 256): 0 = 8 waves / 64-channel steps, 1 = 2 x 4 waves / 32-channel steps
+    if (value != 0 && value != 1) return fail(DSEN2_ERR_INVALID, "bf16 variant %d unknown", value);
+    g_bf16_variant = value;
+    return DSEN2_OK;
+  }
+  if (key == 3) {   // start stagger of the persistent body kernel (quantum in units of 8128 cycles; 0 = off)
+    if (value < 0 || value > 64) return fail(DSEN2_ERR_INVALID, "stagger %d out of range", value);
+    g_body_stagger = value;
     return DSEN2_OK;
   }
   if (key == 2) {   // output-layer kernel: 1 = 16x16x4 (default), 0 = padded 32-wide block
@@ -134,6 +145,7 @@ int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_lay
     L.flat_off = flat;
     flat += (size_t)9 * L.cin * L.cout + L.cout;
     L.bf16 = precision == 1 && L.cin == feature_size && L.cout == feature_size;   // residual-block convolutions only
+    L.bf16_variant = (L.bf16 && feature_size == 256) ? g_bf16_variant : 0;
     L.w_off = dev; dev += align_up(L.bf16 ? (size_t)9 * L.cin * L.cout / 2 : packed_weight_floats(L.geom));
     L.b_off = dev; dev += align_up((size_t)L.geom.cout_pad);
     m->layers.push_back(L);
@@ -161,7 +173,8 @@ int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t coun
     const float* k = host_flat + L.flat_off;
     const float* b = k + (size_t)9 * L.cin * L.cout;
     if (L.bf16)
-      pack_conv_weights_bf16_host(k, L.cin, L.cout, reinterpret_cast<uint16_t*>(staged.data() + L.w_off));
+      pack_conv_weights_bf16_host(k, L.cin, L.cout, bf16_chunk_channels(L.bf16_variant),
+                                  reinterpret_cast<uint16_t*>(staged.data() + L.w_off));
     else
       pack_conv_weights_host(k, L.cin, L.cout, L.geom, staged.data() + L.w_off);
     memcpy(staged.data() + L.b_off, b, sizeof(float) * L.cout);
@@ -194,7 +207,7 @@ static ConvParams make_params(const float* in, const float* wpk, const float* bi
   p.in = in; p.wpk = wpk; p.bias = bias; p.aux = aux; p.out = out; p.out2 = nullptr;
   p.n = n; p.h = h; p.w = w;
   p.tiles_x = (w + kTile - 1) / kTile; p.tiles_y = (h + kTile - 1) / kTile;
-  p.cout_real = cout_real; p.res_scale = scale;
+  p.cout_real = cout_real; p.res_scale = scale; p.stagger = g_body_stagger;
   return p;
 }
 
@@ -232,11 +245,11 @@ int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, cons
       const Layer& LA = m->layers[li++];
       ConvParams pa = make_params(reinterpret_cast<const float*>(abf), P + LA.w_off, P + LA.b_off, nullptr,
                                   reinterpret_cast<float*>(tbf), n, h, w, 0, 0.f);
-      HIP_TRY(launch_conv3x3_body_bf16(pa, m->feat, kEpiRelu, stream));
+      HIP_TRY(launch_conv3x3_body_bf16(pa, m->feat, kEpiRelu, LA.bf16_variant, stream));
       const Layer& LB = m->layers[li++];
       ConvParams pb = make_params(reinterpret_cast<const float*>(tbf), P + LB.w_off, P + LB.b_off, a, a, n, h, w, 0, 0.1f);
       pb.out2 = abf;
-      HIP_TRY(launch_conv3x3_body_bf16(pb, m->feat, kEpiResidual, stream));
+      HIP_TRY(launch_conv3x3_body_bf16(pb, m->feat, kEpiResidual, LB.bf16_variant, stream));
     }
   } else
   for (int i = 0; i < m->num_layers; ++i) {      // DSen2Net.py:31-32 -> :9-15
@@ -291,7 +304,8 @@ int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, c
   hipStream_t stream = (hipStream_t)stream_;
   const size_t wn = (size_t)9 * feat * feat;
   std::vector<uint16_t> wb(wn);
-  pack_conv_weights_bf16_host(host_kernel, feat, feat, wb.data());
+  const int variant = feat == 256 ? g_bf16_variant : 0;
+  pack_conv_weights_bf16_host(host_kernel, feat, feat, bf16_chunk_channels(variant), wb.data());
   char* dev = nullptr;
   HIP_TRY(hipMalloc((void**)&dev, wn * 2 + feat * sizeof(float)));
   hipError_t e = hipMemcpy(dev, wb.data(), wn * 2, hipMemcpyHostToDevice);
@@ -301,7 +315,7 @@ int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, c
                                reinterpret_cast<const float*>(dev + wn * 2), dev_aux, reinterpret_cast<float*>(dev_out),
                                n, h, w, 0, res_scale);
     p.out2 = dev_out2_bf16;
-    e = launch_conv3x3_body_bf16(p, feat, epilogue, stream);
+    e = launch_conv3x3_body_bf16(p, feat, epilogue, variant, stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFree(dev);
@@ -325,7 +339,8 @@ int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, c
   // bf16 copy right behind it (dev_out must then hold 1.5 fp32 tensors)
   if (L.bf16 && L.epilogue == kEpiResidual) p.out2 = dev_out + (size_t)n * h * w * m->feat;
   auto launch = [&]() -> hipError_t {
-    return L.bf16 ? launch_conv3x3_body_bf16(p, m->feat, L.epilogue, stream) : launch_conv3x3(p, L.geom, L.epilogue, stream);
+    return L.bf16 ? launch_conv3x3_body_bf16(p, m->feat, L.epilogue, L.bf16_variant, stream)
+                  : launch_conv3x3(p, L.geom, L.epilogue, stream);
   };
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));

@@ -110,6 +110,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   if (lid >= n_items) return;
   const int my_items = (n_items - lid + G - 1) / G;
+  // Start stagger: all workgroups run the same program on equal work, so left alone they stay in lockstep and
+  // every CU's epilogue (a burst of stores at several TB/s chip-wide) falls in the same few microseconds while
+  // the matrix pipes idle.  Delaying workgroup k by (k mod 4) quarter-items spreads the bursts under other
+  // workgroups' MFMA phases.  p.stagger = delay quantum in units of s_sleep 127 (8128 cycles); 0 = off.
+  for (int d = (bid >> 3 & 3) * p.stagger; d > 0; --d) __builtin_amdgcn_s_sleep(127);
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const size_t img_pix = (size_t)p.h * p.w;
 
@@ -448,6 +453,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
 }
 
 int g_body_ablate = 0;
+int g_body_stagger = 0;
 
 template <int CIN, int COUT, int EPI, int KC = 32, int NWAVES = 8, int ABL = 0, bool LT = false, bool BF16 = false>
 static hipError_t launch_body_one(const ConvParams& p, hipStream_t stream) {
@@ -501,8 +507,20 @@ hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int 
 }
 
 // bf16 operands, fp32 accumulate: F -> F with F = 128 or 256 (CIN template argument = F/2 words per pixel)
-hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, hipStream_t stream) {
+hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream) {
   if (epilogue == kEpiResidual && !p.out2) return hipErrorInvalidValue;
+  if (variant == 1 && feat == 256)    // two 4-wave workgroups per CU, 32-channel steps, wave tile 64 ch x 128 px
+    return epilogue == kEpiRelu ? launch_body_one<128, 256, kEpiRelu, 16, 4, 0, false, true>(p, stream)
+                                : launch_body_one<128, 256, kEpiResidual, 16, 4, 0, false, true>(p, stream);
+  if (g_body_ablate != 0 && feat == 256) {
+#define DSEN2_ABL(M)                                                                                         \
+  if (g_body_ablate == M)                                                                                    \
+    return epilogue == kEpiRelu ? launch_body_one<128, 256, kEpiRelu, 32, 8, M, false, true>(p, stream)      \
+                                : launch_body_one<128, 256, kEpiResidual, 32, 8, M, false, true>(p, stream);
+    DSEN2_ABL(1) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31)
+#undef DSEN2_ABL
+    return hipErrorInvalidValue;
+  }
   if (feat == 256 && epilogue == kEpiRelu) return launch_body_one<128, 256, kEpiRelu, 32, 8, 0, false, true>(p, stream);
   if (feat == 256 && epilogue == kEpiResidual) return launch_body_one<128, 256, kEpiResidual, 32, 8, 0, false, true>(p, stream);
   if (feat == 128 && epilogue == kEpiRelu) return launch_body_one<64, 128, kEpiRelu, 32, 8, 0, false, true>(p, stream);

@@ -314,17 +314,19 @@ static inline uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
-void pack_conv_weights_bf16_host(const float* k, int cin, int cout, uint16_t* dst) {
-  // [slab][cc (64 channels)][tap][g (8 channels)][o (128)][j (8)]: one (slab, cc, tap) chunk = 16 KiB, the LDS image
-  const int ncc = cin / 64, nslab = cout / 128;
+int g_bf16_variant = 0;   // tuning key 4: 0 = one 8-wave workgroup per CU, 64-channel steps; 1 = two 4-wave workgroups, 32-channel steps
+
+void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch, uint16_t* dst) {
+  // [slab][cc (chunk_ch channels)][tap][g (8 channels)][o (128)][j (8)]: one (slab, cc, tap) chunk is the LDS image
+  const int ncc = cin / chunk_ch, nslab = cout / 128, ng = chunk_ch / 8;
   size_t i = 0;
   for (int slab = 0; slab < nslab; ++slab)
     for (int cc = 0; cc < ncc; ++cc)
       for (int tap = 0; tap < 9; ++tap)
-        for (int g = 0; g < 8; ++g)
+        for (int g = 0; g < ng; ++g)
           for (int o = 0; o < 128; ++o)
             for (int j = 0; j < 8; ++j, ++i) {
-              const int c = cc * 64 + 8 * g + j, oc = slab * 128 + o;
+              const int c = cc * chunk_ch + 8 * g + j, oc = slab * 128 + o;
               dst[i] = f32_to_bf16_rne(k[((size_t)tap * cin + c) * cout + oc]);
             }
 }
