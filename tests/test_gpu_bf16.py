@@ -72,3 +72,26 @@ def test_bf16_network_vs_fp32_oracle():
         print('d=%d F=%d: bf16 rmse %.3e (%.2e of signal rms %.2f), fp32 rmse %.3e' % (d, f, e16, e16 / scale, scale, e32))
         assert e32 < 5e-6
         assert e16 / scale < 5e-3                                   # bf16-appropriate gate: 0.5 % of signal rms
+
+
+def test_bf16_network_ragged_and_variant():
+    """Ragged image size through the bf16 network, both kernel structures (tuning key 4)."""
+    from dsen2_amd import _lib
+    from dsen2_amd.DSen2Net import s2model
+    flat = do.he_uniform_weights(10, 6, 3, 256, seed=9, bias_scale=0.05)
+    xs = do.synthetic_inputs(1, 21, 37, (4, 6), seed=9)
+    ref = c_oracle.forward(xs, flat, 3, 256)
+    scale = float(np.sqrt(np.mean(ref ** 2)))
+    outs = []
+    try:
+        for v in (0, 1):
+            _lib.call('dsen2_set_tuning', 4, v)
+            m = s2model(((4, None, None), (6, None, None)), num_layers=3, feature_size=256, precision='bf16')
+            m.set_weights_flat(flat)
+            outs.append(m.predict(xs))
+            assert do.rmse(outs[-1], ref) / scale < 5e-3
+    finally:
+        _lib.call('dsen2_set_tuning', 4, 0)
+    # same products, same fp32 accumulation order per output element? (64- vs 32-channel steps differ only in
+    # where the k loop is cut, not in its order) -> the two structures agree to fp32 rounding of the bf16 copies
+    assert np.abs(outs[0] - outs[1]).max() < 1e-2 * scale

@@ -98,3 +98,21 @@ def test_forward_errors():
         m.set_weights_flat(np.zeros(10, np.float32))             # wrong parameter count
     with pytest.raises(_lib.DSen2Error):
         s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=100)
+
+
+def test_empty_batch_returns_empty():
+    flat = do.he_uniform_weights(10, 6, 6, 128, seed=1)
+    m = _model((4, 6), 6, 128, flat)
+    y = m.predict([np.zeros((0, 4, 32, 32), np.float32), np.zeros((0, 6, 32, 32), np.float32)])
+    assert y.shape == (0, 6, 32, 32) and y.dtype == np.float32
+
+
+def test_single_pixel_and_tiny_images():
+    """Smallest legal shapes: 1x1 and 3x5 images exercise the zero-padding select and the ragged-tile path alone."""
+    flat = do.he_uniform_weights(10, 6, 6, 128, seed=2, bias_scale=0.05)
+    m = _model((4, 6), 6, 128, flat)
+    for h, w in [(1, 1), (3, 5), (17, 16)]:
+        xs = do.synthetic_inputs(2, h, w, (4, 6), seed=h * 10 + w)
+        y = m.predict(xs)
+        ref = c_oracle.forward(xs, flat, 6, 128)
+        assert do.rmse(y, ref) < 5e-6, (h, w)
