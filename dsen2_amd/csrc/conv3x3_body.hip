@@ -509,6 +509,8 @@ hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int 
 // bf16 operands, fp32 accumulate: F -> F with F = 128 or 256 (CIN template argument = F/2 words per pixel)
 hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream) {
   if (epilogue == kEpiResidual && !p.out2) return hipErrorInvalidValue;
+  if (variant == 2 && feat == 256 && g_body_ablate == 0 && bodyd_supports(p, 256))
+    return launch_conv3x3_bodyd(p, 256, epilogue, true, stream);
   if (variant == 1 && feat == 256)    // two 4-wave workgroups per CU, 32-channel steps, wave tile 64 ch x 128 px
     return epilogue == kEpiRelu ? launch_body_one<128, 256, kEpiRelu, 16, 4, 0, false, true>(p, stream)
                                 : launch_body_one<128, 256, kEpiResidual, 16, 4, 0, false, true>(p, stream);

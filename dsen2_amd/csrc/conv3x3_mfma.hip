@@ -268,8 +268,9 @@ static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
 }
 
 int g_out_variant = 1;    // 1 = 16x16x4 output-layer kernel (conv3x3_out.hip); 0 = padded 32-wide block of this file
-int g_body_variant = 4;   // tuning knob (dsen2_set_tuning): structure used for F->F body convs packed from now on
-                          // 4 = persistent pipelined kernel (conv3x3_body.hip); 0 = one tile per workgroup; 1-3 = A/B variants
+int g_body_variant = 8;   // tuning knob (dsen2_set_tuning): structure used for F->F body convs packed from now on
+                          // 8 = persistent kernel with deferred epilogue (conv3x3_bodyd.hip; falls back to 4 where it does
+                          // not apply); 4 = persistent kernel (conv3x3_body.hip); 0 = one tile per workgroup; 1-3, 5, 6 = A/B variants
 
 bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
   if (cin <= 0 || cout <= 0) return false;
@@ -286,7 +287,7 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
     *g = PackGeom{(v == 1 || v == 2 || v == 5) ? 16 : 32, 128, cin, cout, v};
     return true;
   }
-  if (cin == 256 && cout == 256) { *g = PackGeom{32, 128, cin, cout, g_body_variant >= 4 ? 4 : 0}; return true; }
+  if (cin == 256 && cout == 256) { *g = PackGeom{32, 128, cin, cout, g_body_variant >= 4 ? 4 : 0}; return true; }   // no deferred form (8 chunks)
   return false;
 }
 
@@ -314,7 +315,8 @@ static inline uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
-int g_bf16_variant = 0;   // tuning key 4: 0 = one 8-wave workgroup per CU, 64-channel steps; 1 = two 4-wave workgroups, 32-channel steps
+int g_bf16_variant = 2;   // tuning key 4: 2 = deferred-epilogue kernel (falls back to 0); 0 = one 8-wave workgroup per CU,
+                          // 64-channel steps; 1 = two 4-wave workgroups, 32-channel steps
 
 void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch, uint16_t* dst) {
   // [slab][cc (chunk_ch channels)][tap][g (8 channels)][o (128)][j (8)]: one (slab, cc, tap) chunk is the LDS image
@@ -334,8 +336,11 @@ void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, hipStream_t stream) {
   const int cin_pad = geom.cin_pad, cout_pad = geom.cout_pad;
   if (geom.variant == 7 && epilogue == kEpiSkipNCHW) return launch_conv3x3_out(p, cin_pad, stream);
+  if (geom.variant == 8 && cin_pad == 128 && cout_pad == 128 && epilogue != kEpiSkipNCHW && g_body_ablate == 0 &&
+      bodyd_supports(p, 128))
+    return launch_conv3x3_bodyd(p, 128, epilogue, false, stream);
   if (geom.variant >= 4 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)
-    return launch_conv3x3_body(p, cin_pad, epilogue, geom.variant, stream);
+    return launch_conv3x3_body(p, cin_pad, epilogue, geom.variant == 8 ? 4 : geom.variant, stream);
   if (cin_pad == 128 && cout_pad == 128 && epilogue != kEpiSkipNCHW && geom.variant != 0) {
     const bool relu = epilogue == kEpiRelu;
     switch (geom.variant) {

@@ -49,12 +49,15 @@ extern int g_out_variant;
 hipError_t launch_conv3x3_out(const ConvParams& p, int feat, hipStream_t stream);
 extern int g_body_stagger;  // tuning key 3
 extern int g_body_ablate;   // timing-only ablation mask of the persistent body kernel (0 = off)
+// deferred-epilogue persistent kernel (conv3x3_bodyd.hip): fp32 F=128 and bf16 F=256 only, tensors < 4 GiB
+bool bodyd_supports(const ConvParams& p, int cout);
+hipError_t launch_conv3x3_bodyd(const ConvParams& p, int feat, int epilogue, bool bf16, hipStream_t stream);
 // bf16-operand form of the persistent kernel: in bf16 NHWC, weights packed by pack_conv_weights_bf16_host
 hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream);
 // kernel HWIO fp32 -> bf16 packed [slab][cc(64 ch)][tap][g(8 groups of 8 ch)][o(128)][8]; dst holds 9*cin*cout uint16
 void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, int chunk_ch, uint16_t* dst);
 extern int g_bf16_variant;   // tuning key 4 (read when weights are packed and when the kernel is launched)
-inline int bf16_chunk_channels(int variant) { return variant == 1 ? 32 : 64; }
+inline int bf16_chunk_channels(int variant) { return variant == 1 ? 32 : 64; }   // variants 0 and 2 share the packing
 hipError_t launch_f32_to_bf16(const float* in, void* out_bf16, size_t count, hipStream_t stream);
 // persistent pipelined F->F kernel (conv3x3_body.hip); weights packed with KC=32, NT=128
 hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream);
