@@ -63,12 +63,12 @@ const char* dsen2_last_error(void) { return g_err; }
 
 int dsen2_set_tuning(int key, int value) {
   if (key == 0) {
-    if (value < 0 || value > 8 || value == 7) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
+    if (value < 0 || value > 10 || value == 7) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
     g_body_variant = value;
     return DSEN2_OK;
   }
   if (key == 4) {   // bf16 body kernel structure (F = 256): 0 = 8 waves / 64-channel steps, 1 = 2 x 4 waves / 32-channel steps
-    if (value < 0 || value > 2) return fail(DSEN2_ERR_INVALID, "bf16 variant %d unknown", value);
+    if (value < 0 || value > 3) return fail(DSEN2_ERR_INVALID, "bf16 variant %d unknown", value);
     g_bf16_variant = value;
     return DSEN2_OK;
   }

@@ -15,6 +15,8 @@
 //     LDS latency and the barrier sit behind MFMAs that are already queued on the matrix pipe.
 //
 // One step = one (tap, 32-channel chunk) = 64 MFMAs per wave (4 k-steps x 4 accumulators x 4).
+#include <type_traits>
+
 #include "dsen2_internal.h"
 
 namespace dsen2 {
@@ -79,7 +81,7 @@ struct BodyCfg {
 // k = 8*(l>>5) .. +7, exactly the 8 consecutive channels one ds_read_b128 returns).  fp32 accumulate; kEpiRelu
 // writes bf16; kEpiResidual keeps the residual stream in fp32 (aux/out) and also writes its bf16 copy (out2),
 // which is what the next block's first convolution reads.
-template <int CIN, int COUT, int EPI, int KC, int NWAVES, int ABL = 0, bool LT = false, bool BF16 = false>
+template <int CIN, int COUT, int EPI, int KC, int NWAVES, int ABL = 0, bool LT = false, bool BF16 = false, bool STG = false>
 __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const ConvParams p, const int n_items) {
   using B = BodyCfg<KC, NWAVES>;
   constexpr int NT = B::NT, THREADS = B::THREADS, PSTR = B::PSTR, IN_FLOATS = B::IN_FLOATS, WCH = B::WCH;
@@ -220,6 +222,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
   };
   read_frags(w_cur, x_cur, in_s, w_s, 0, 0);
 
+  // STG: the item loop exists twice, selected per wave at the top level: waves 0-3 stage (LDS writes + next loads)
+  // ahead of k-step 0, waves 4-7 ahead of k-step KSTEPS/2, so the two waves of a SIMD are half a step apart.
+  auto run = [&](auto mid_c) {
+  constexpr int MIDS = decltype(mid_c)::value;
   for (int it = 0; it < my_items; ++it) {
     const int item = lid + it * G;
     const bool have_next_item = it + 1 < my_items;
@@ -305,14 +311,14 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
             // next chunk: other input buffer (next cc, or the next item's chunk 0 which also lives there)
             read_frags(w_nxt, x_nxt, ib_next, wb_nx, 0, 0);
           }
-          if (s == KSTEPS / 2 - 1) {
+          if (s == MIDS) {
             // mid-step: the pieces in flight go to LDS here, so the end of the step is only the barrier
             // (nothing freshly written sits right behind it)
             if constexpr (!(ABL & 4)) store_w(wr);
             if constexpr (!(ABL & 8))
               if (tap < IN_ROUNDS) store_in(ib_next, tap < IN_ROUNDS ? tap : 0, ir);
           }
-          if (LT ? s == KSTEPS - 1 : s == KSTEPS / 2 - 1) {
+          if (LT ? s == KSTEPS - 1 : s == MIDS) {
             // issue the global loads of the pieces the NEXT step writes (LT: before this step's last 16 MFMAs;
             // otherwise right after this step's own LDS writes, which frees the staging registers first)
             if constexpr (!(ABL & 4)) load_w(wr);
@@ -450,15 +456,24 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void conv3x3_body_kernel(const Conv
     }
     }   // transposed (residual) epilogue
   }
+  };   // run
+  if constexpr (STG) {
+    if (wave < NWAVES / 2)
+      run(std::integral_constant<int, 0>{});
+    else
+      run(std::integral_constant<int, KSTEPS / 2>{});
+  } else {
+    run(std::integral_constant<int, KSTEPS / 2 - 1>{});
+  }
 }
 
 int g_body_ablate = 0;
 int g_body_stagger = 0;
 
-template <int CIN, int COUT, int EPI, int KC = 32, int NWAVES = 8, int ABL = 0, bool LT = false, bool BF16 = false>
+template <int CIN, int COUT, int EPI, int KC = 32, int NWAVES = 8, int ABL = 0, bool LT = false, bool BF16 = false, bool STG = false>
 static hipError_t launch_body_one(const ConvParams& p, hipStream_t stream) {
   using B = BodyCfg<KC, NWAVES>;
-  auto kern = conv3x3_body_kernel<CIN, COUT, EPI, KC, NWAVES, ABL, LT, BF16>;
+  auto kern = conv3x3_body_kernel<CIN, COUT, EPI, KC, NWAVES, ABL, LT, BF16, STG>;
   static bool attr_set[64] = {};
   static int cus[64] = {};
   int dev = 0;
@@ -482,6 +497,10 @@ static hipError_t launch_body_one(const ConvParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream) {
+  if (variant == 9 && feat == 128) {     // A/B: wave-group stagger of the staging slot
+    return epilogue == kEpiRelu ? launch_body_one<128, 128, kEpiRelu, 32, 8, 0, false, false, true>(p, stream)
+                                : launch_body_one<128, 128, kEpiResidual, 32, 8, 0, false, false, true>(p, stream);
+  }
   if (variant == 6 && feat == 128) {     // A/B: loads issued at the tail of the step
     return epilogue == kEpiRelu ? launch_body_one<128, 128, kEpiRelu, 32, 8, 0, true>(p, stream)
                                 : launch_body_one<128, 128, kEpiResidual, 32, 8, 0, true>(p, stream);
@@ -509,7 +528,12 @@ hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int 
 // bf16 operands, fp32 accumulate: F -> F with F = 128 or 256 (CIN template argument = F/2 words per pixel)
 hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream) {
   if (epilogue == kEpiResidual && !p.out2) return hipErrorInvalidValue;
-  if (variant == 2 && feat == 256 && g_body_ablate == 0 && bodyd_supports(p, 256))
+  // default (2): conv-B on the deferred-epilogue kernel, conv-A on the wave-group-staggered persistent kernel
+  if (variant == 2 && feat == 256 && g_body_ablate == 0 && epilogue == kEpiResidual && bodyd_supports(p, 256))
+    return launch_conv3x3_bodyd(p, 256, epilogue, true, stream);
+  if (variant == 2 && feat == 256 && g_body_ablate == 0 && epilogue == kEpiRelu)
+    return launch_body_one<128, 256, kEpiRelu, 32, 8, 0, false, true, true>(p, stream);
+  if (variant == 3 && feat == 256 && bodyd_supports(p, 256))      // A/B: deferred kernel for both epilogues
     return launch_conv3x3_bodyd(p, 256, epilogue, true, stream);
   if (variant == 1 && feat == 256)    // two 4-wave workgroups per CU, 32-channel steps, wave tile 64 ch x 128 px
     return epilogue == kEpiRelu ? launch_body_one<128, 256, kEpiRelu, 16, 4, 0, false, true>(p, stream)

@@ -284,7 +284,7 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
   if (cin <= 16) { *g = PackGeom{16, 128, 16, cout, 0}; return true; }
   if (cin == 128 && cout == 128) {
     const int v = g_body_variant;
-    *g = PackGeom{(v == 1 || v == 2 || v == 5) ? 16 : 32, 128, cin, cout, v};
+    *g = PackGeom{(v == 1 || v == 2 || v == 5) ? 16 : 32, 128, cin, cout, v};   // 8, 9, 10 share variant 4's packing
     return true;
   }
   if (cin == 256 && cout == 256) { *g = PackGeom{32, 128, cin, cout, g_body_variant >= 4 ? 4 : 0}; return true; }   // no deferred form (8 chunks)
@@ -336,11 +336,17 @@ void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, hipStream_t stream) {
   const int cin_pad = geom.cin_pad, cout_pad = geom.cout_pad;
   if (geom.variant == 7 && epilogue == kEpiSkipNCHW) return launch_conv3x3_out(p, cin_pad, stream);
-  if (geom.variant == 8 && cin_pad == 128 && cout_pad == 128 && epilogue != kEpiSkipNCHW && g_body_ablate == 0 &&
+  // default (8): conv-B (residual) on the deferred-epilogue kernel; conv-A (ReLU) on the persistent kernel with the
+  // wave-group stagger (variant 9) — measured best of {4, 8, 9} for each epilogue (tools/ab_body_conv.py)
+  if (geom.variant == 8 && cin_pad == 128 && cout_pad == 128 && epilogue == kEpiResidual && g_body_ablate == 0 &&
       bodyd_supports(p, 128))
     return launch_conv3x3_bodyd(p, 128, epilogue, false, stream);
+  if (geom.variant == 8 && cin_pad == 128 && cout_pad == 128 && epilogue == kEpiRelu && g_body_ablate == 0)
+    return launch_conv3x3_body(p, cin_pad, epilogue, 9, stream);
+  if (geom.variant == 10 && cin_pad == 128 && cout_pad == 128 && epilogue != kEpiSkipNCHW && bodyd_supports(p, 128))
+    return launch_conv3x3_bodyd(p, 128, epilogue, false, stream);      // A/B: deferred kernel for both epilogues
   if (geom.variant >= 4 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)
-    return launch_conv3x3_body(p, cin_pad, epilogue, geom.variant == 8 ? 4 : geom.variant, stream);
+    return launch_conv3x3_body(p, cin_pad, epilogue, (geom.variant == 8 || geom.variant == 10) ? 4 : geom.variant, stream);
   if (cin_pad == 128 && cout_pad == 128 && epilogue != kEpiSkipNCHW && geom.variant != 0) {
     const bool relu = epilogue == kEpiRelu;
     switch (geom.variant) {
