@@ -34,8 +34,17 @@ def default_device():
 
 
 def _to_device_f32(a, device):
+    """Any real array -> contiguous float32 CUDA tensor (the reference's float32 patch arrays take any dtype).
+    Integer rasters (Sentinel-2 L1C is uint16) are uploaded as they are and widened on the GPU: half the PCIe
+    bytes and no host-side conversion pass (0.15 s of a 10980^2 tile)."""
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=torch.float32).contiguous()
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint16:
+        t = torch.from_numpy(a.view(np.int16)).to(device)
+        return (t.to(torch.int32) & 0xFFFF).to(torch.float32)
+    if a.dtype in (np.int16, np.uint8, np.int8, np.int32):
+        return torch.from_numpy(a).to(device).to(torch.float32)
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
 
 

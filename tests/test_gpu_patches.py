@@ -118,3 +118,18 @@ def test_large_image_round_trip_and_oracle():
     o10, o20 = po.get_test_patches(d10, d20, patchSize=128, border=8, f32_coords=True)
     assert np.array_equal(p10, o10)
     np.testing.assert_allclose(p20, o20, **TIGHT)
+
+
+def test_integer_rasters_are_widened_on_device(golden_dir):
+    """uint16 / int16 / int32 inputs give exactly the patches of their float32 conversion (values up to 65535)."""
+    from dsen2_amd import patches as gp
+    rng = np.random.default_rng(5)
+    d10 = rng.integers(0, 65536, size=(72, 72, 4)).astype(np.uint16)
+    d20 = rng.integers(0, 65536, size=(36, 36, 6)).astype(np.uint16)
+    ref = gp.get_test_patches(d10.astype(np.float32), d20.astype(np.float32), patchSize=32, border=4)
+    for cast in (lambda a: a, lambda a: a.astype(np.int32), lambda a: (a // 2).astype(np.int16)):
+        a10, a20 = cast(d10), cast(d20)
+        got = gp.get_test_patches(a10, a20, patchSize=32, border=4)
+        want = ref if cast(d10).dtype != np.int16 else gp.get_test_patches(a10.astype(np.float32), a20.astype(np.float32),
+                                                                            patchSize=32, border=4)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
