@@ -19,9 +19,11 @@ for v in (0, TEST_VARIANT):
     models[v].set_weights_flat(flat)
 _lib.call('dsen2_set_tuning', 0, 8)
 bad_total = 0
-for B in (3, 64, 65, 200, 512):
-    for rep in range(6):
-        a = torch.randn((B, 32, 32, 128), device='cuda'); r = torch.randn((B, 32, 32, 128), device='cuda')
+SHAPES = [(3, 32, 32, 6), (64, 32, 32, 6), (65, 32, 32, 6), (200, 32, 32, 6), (512, 32, 32, 6),
+          (5, 128, 128, 3), (2, 192, 192, 2), (7, 21, 37, 3), (40, 50, 17, 3), (1, 16, 16, 3), (300, 16, 16, 3)]
+for B, HH, WW, REPS in SHAPES:
+    for rep in range(REPS):
+        a = torch.randn((B, HH, WW, 128), device='cuda'); r = torch.randn((B, HH, WW, 128), device='cuda')
         for layer in (1, 2):
             o0 = torch.empty_like(a); o4 = torch.empty_like(a)
             models[0].time_body_conv(layer, a, r if layer == 2 else None, o0, iters=1)
@@ -29,6 +31,6 @@ for B in (3, 64, 65, 200, 512):
             nbad = int(((o4 - o0).abs() > 1e-4).sum())
             bad_total += nbad
             if nbad:
-                print('MISMATCH B=%d rep=%d layer=%d: %d elements' % (B, rep, layer, nbad))
+                print('MISMATCH B=%d %dx%d rep=%d layer=%d: %d elements' % (B, HH, WW, rep, layer, nbad))
 print('stress: total mismatching elements = %d' % bad_total)
 sys.exit(1 if bad_total else 0)
