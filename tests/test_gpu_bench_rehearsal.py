@@ -34,3 +34,15 @@ def test_bench_single_gpu_line_has_contract_fields():
         assert k in r, k
     assert r['dtype'] == 'f32' and r['vs_baseline'] is None and r['roofline']['bound'] == 'mfma'
     assert 0 < r['roofline']['frac'] <= 1 and r['cpu_baseline']['kind'] == 'port'
+
+
+def test_full_tile_two_ranks_gloo_matches_single_rank():
+    """supres._run patch sharding + dist.gather_patches with 2 ranks (gloo, both on the one GPU): the image every
+    rank returns equals the single-rank image bit for bit."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29733', os.path.join(ROOT, 'tools', 'bench_full_tile.py'), '--size', '600',
+           '--skip60', '--backend', 'gloo', '--check']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert r['n_gpus'] == 2 and r['patches20'] == 36 and r['matches_single_rank'] is True

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""BASELINE configs[3] on ONE GPU: DSen2_20 + DSen2_60 over a synthetic full-size Sentinel-2 tile
-(10980 x 10980 @10 m), end to end through the drop-in surface (host ndarray in, host ndarray out).
+"""BASELINE configs[3]: DSen2_20 + DSen2_60 over a synthetic full-size Sentinel-2 tile (10980 x 10980 @10 m),
+end to end through the drop-in surface (host ndarray in, host ndarray out), on one GPU or patch-sharded over the
+GPUs of a node (one process per GPU, RCCL all-gather of the predictions: dsen2_amd/dist.py).
 
     python tools/bench_full_tile.py [--size 10980] [--skip60]
-Prints one JSON line with wall times of the stages.  Random-init weights; the data is synthetic.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_full_tile.py
+    (--backend gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks)
+Rank 0 prints one JSON line with wall times.  Random-init weights; the data is synthetic.
 """
 import argparse
 import contextlib
@@ -23,7 +26,22 @@ from dsen2_amd import supres, weights        # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--size', type=int, default=10980)
 ap.add_argument('--skip60', action='store_true')
+ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'])
+ap.add_argument('--check', action='store_true', help='multi-rank: also verify the result against a single-rank run')
 args = ap.parse_args()
+
+import torch.distributed as td      # noqa: E402
+world = int(os.environ.get('WORLD_SIZE', '1'))
+rank = int(os.environ.get('RANK', '0'))
+local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+dev_index = local_rank if args.backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+torch.cuda.set_device(dev_index)
+if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if args.backend == 'nccl':
+        td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev_index))
+    else:
+        td.init_process_group('gloo', rank=rank, world_size=world)
 
 n = args.size - args.size % 6
 rng = np.random.default_rng(0)
@@ -34,7 +52,7 @@ tmp = tempfile.mkdtemp()
 np.save(os.path.join(tmp, 's2_032_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 6, 128, seed=11))
 np.save(os.path.join(tmp, 's2_030_lr_1e-05.npy'), weights.random_he_uniform(12, 2, 6, 128, seed=12))
 supres.MDL_PATH = os.path.join(tmp, '')
-out = {'tile': [n, n], 'data': 'synthetic', 'patches20': int(np.ceil(n / 112.0) ** 2), 'patches60': int(np.ceil(n / 168.0) ** 2)}
+out = {'tile': [n, n], 'data': 'synthetic', 'n_gpus': world, 'patches20': int(np.ceil(n / 112.0) ** 2), 'patches60': int(np.ceil(n / 168.0) ** 2)}
 
 
 def timed(fn, *a):
@@ -61,4 +79,14 @@ if not args.skip60:
     out['dsen2_60_equiv_32x32_patches_per_s'] = round(out['patches60'] * 36 / t60, 1)
     assert y60.shape == (n, n, 2)
 out['peak_gpu_mem_gib'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
-print(json.dumps(out))
+if world > 1 and args.check:
+    td.barrier()
+    td.destroy_process_group()            # dist.rank_world() now reports (0, 1): every rank computes everything
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = supres.DSen2_20(d10, d20)
+    out['matches_single_rank'] = bool(np.array_equal(ref, y20))
+if rank == 0:
+    print(json.dumps(out))
+if world > 1 and td.is_initialized():
+    td.barrier()
+    td.destroy_process_group()
