@@ -8,22 +8,22 @@ from dsen2_amd.DSen2Net import s2model
 H, F, B = 32, 256, 256
 flat = W.random_he_uniform(10, 6, 2, F, seed=1, bias_scale=0.05)
 ms = {}
-for v in (0, 2, 3):
+for v in (0, 1, 2, 3):
     _lib.call('dsen2_set_tuning', 4, v)
     ms[v] = s2model(((4, None, None), (6, None, None)), num_layers=2, feature_size=F, precision='bf16'); ms[v].set_weights_flat(flat)
 _lib.call('dsen2_set_tuning', 4, 0)
 a = torch.randn((B, H, H, F), device='cuda').to(torch.bfloat16); r = torch.randn((B, H, H, F), device='cuda')
 outs = {}
-for v in (0, 2, 3):
+for v in (0, 1, 2, 3):
     o = torch.empty((B * 3 // 2 + 1, H, H, F), device='cuda'); ms[v].time_body_conv(2, a, r, o, iters=1); outs[v] = o[:B].clone()
 print('variant 2 vs 0 max diff (residual layer):', (outs[2] - outs[0]).abs().max().item())
-res = {v: {'relu': [], 'res': []} for v in (0, 2, 3)}
+res = {v: {'relu': [], 'res': []} for v in (0, 1, 2, 3)}
 o = torch.empty((B * 3 // 2 + 1, H, H, F), device='cuda')
 for rnd in range(5):
-    for v in (0, 2, 3):
+    for v in (0, 1, 2, 3):
         res[v]['relu'].append(ms[v].time_body_conv(1, a, None, o, iters=10))
         res[v]['res'].append(ms[v].time_body_conv(2, a, r, o, iters=10))
 flops = B * H * H * 2 * 9 * F * F
-for v in (0, 2, 3):
+for v in (0, 1, 2, 3):
     tr, ts = float(np.median(res[v]['relu'])), float(np.median(res[v]['res']))
     print(json.dumps({'variant': v, 'relu_ms': round(tr, 4), 'res_ms': round(ts, 4), 'relu_tflops': round(flops / tr / 1e9, 1), 'res_tflops': round(flops / ts / 1e9, 1)}))
