@@ -71,6 +71,13 @@ def load():
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = lib
+        # DSEN2_TUNING="key=value,key=value": dsen2_set_tuning() calls applied at load time (A/B runs of whole
+        # scripts and test suites against a non-default kernel structure; see include/dsen2_hip.h for the keys)
+        for kv in filter(None, os.environ.get('DSEN2_TUNING', '').split(',')):
+            key, value = kv.split('=')
+            code = lib.dsen2_set_tuning(int(key), int(value))
+            if code != OK:
+                raise DSen2Error(code, lib.dsen2_last_error().decode('utf-8', 'replace'))
     return _lib
 
 

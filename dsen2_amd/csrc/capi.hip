@@ -67,8 +67,8 @@ int dsen2_set_tuning(int key, int value) {
     g_body_variant = value;
     return DSEN2_OK;
   }
-  if (key == 4) {   // bf16 body kernel structure (F = 256): 0 = 8 waves / 64-channel steps, 1 = 2 x 4 waves / 32-channel steps
-    if (value < 0 || value > 3) return fail(DSEN2_ERR_INVALID, "bf16 variant %d unknown", value);
+  if (key == 4) {   // bf16 body kernel structure (F = 256): see launch_conv3x3_body_bf16; 4 = 16x16x32 form (conv3x3_body16.hip)
+    if (value < 0 || value > 4) return fail(DSEN2_ERR_INVALID, "bf16 variant %d unknown", value);
     g_bf16_variant = value;
     return DSEN2_OK;
   }
@@ -173,7 +173,7 @@ int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t coun
     const float* k = host_flat + L.flat_off;
     const float* b = k + (size_t)9 * L.cin * L.cout;
     if (L.bf16)
-      pack_conv_weights_bf16_host(k, L.cin, L.cout, bf16_chunk_channels(L.bf16_variant),
+      pack_conv_weights_bf16_host(k, L.cin, L.cout, bf16_chunk_channels(L.bf16_variant), bf16_perm16(L.bf16_variant),
                                   reinterpret_cast<uint16_t*>(staged.data() + L.w_off));
     else
       pack_conv_weights_host(k, L.cin, L.cout, L.geom, staged.data() + L.w_off);
@@ -305,7 +305,7 @@ int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, c
   const size_t wn = (size_t)9 * feat * feat;
   std::vector<uint16_t> wb(wn);
   const int variant = feat == 256 ? g_bf16_variant : 0;
-  pack_conv_weights_bf16_host(host_kernel, feat, feat, bf16_chunk_channels(variant), wb.data());
+  pack_conv_weights_bf16_host(host_kernel, feat, feat, bf16_chunk_channels(variant), bf16_perm16(variant), wb.data());
   char* dev = nullptr;
   HIP_TRY(hipMalloc((void**)&dev, wn * 2 + feat * sizeof(float)));
   hipError_t e = hipMemcpy(dev, wb.data(), wn * 2, hipMemcpyHostToDevice);

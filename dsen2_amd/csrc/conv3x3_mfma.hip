@@ -318,7 +318,7 @@ static inline uint16_t f32_to_bf16_rne(float f) {
 int g_bf16_variant = 2;   // tuning key 4: 2 = deferred-epilogue kernel (falls back to 0); 0 = one 8-wave workgroup per CU,
                           // 64-channel steps; 1 = two 4-wave workgroups, 32-channel steps
 
-void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch, uint16_t* dst) {
+void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch, bool perm16, uint16_t* dst) {
   // [slab][cc (chunk_ch channels)][tap][g (8 channels)][o (128)][j (8)]: one (slab, cc, tap) chunk is the LDS image
   const int ncc = cin / chunk_ch, nslab = cout / 128, ng = chunk_ch / 8;
   size_t i = 0;
@@ -328,7 +328,8 @@ void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch
         for (int g = 0; g < ng; ++g)
           for (int o = 0; o < 128; ++o)
             for (int j = 0; j < 8; ++j, ++i) {
-              const int c = cc * chunk_ch + 8 * g + j, oc = slab * 128 + o;
+              const int ch = perm16 ? 32 * (o >> 5) + 8 * ((o & 15) >> 2) + 4 * ((o >> 4) & 1) + (o & 3) : o;
+              const int c = cc * chunk_ch + 8 * g + j, oc = slab * 128 + ch;
               dst[i] = f32_to_bf16_rne(k[((size_t)tap * cin + c) * cout + oc]);
             }
 }

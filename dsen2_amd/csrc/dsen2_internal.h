@@ -55,9 +55,13 @@ hipError_t launch_conv3x3_bodyd(const ConvParams& p, int feat, int epilogue, boo
 // bf16-operand form of the persistent kernel: in bf16 NHWC, weights packed by pack_conv_weights_bf16_host
 hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream);
 // kernel HWIO fp32 -> bf16 packed [slab][cc(64 ch)][tap][g(8 groups of 8 ch)][o(128)][8]; dst holds 9*cin*cout uint16
-void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, int chunk_ch, uint16_t* dst);
+// perm16: row o of a slab holds output channel 32*(o>>5) + 8*((o&15)>>2) + 4*((o>>4)&1) + (o&3) (conv3x3_body16.hip)
+void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, int chunk_ch, bool perm16, uint16_t* dst);
 extern int g_bf16_variant;   // tuning key 4 (read when weights are packed and when the kernel is launched)
-inline int bf16_chunk_channels(int variant) { return variant == 1 ? 32 : 64; }   // variants 0 and 2 share the packing
+inline int bf16_chunk_channels(int variant) { return variant == 1 ? 32 : 64; }   // variants 0, 2, 3 share the packing
+inline bool bf16_perm16(int variant) { return variant == 4; }
+// 16x16x32-MFMA form (conv3x3_body16.hip), F = 256; weights packed with perm16
+hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, hipStream_t stream);
 hipError_t launch_f32_to_bf16(const float* in, void* out_bf16, size_t count, hipStream_t stream);
 // persistent pipelined F->F kernel (conv3x3_body.hip); weights packed with KC=32, NT=128
 hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream);

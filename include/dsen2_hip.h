@@ -42,7 +42,10 @@ int dsen2_device_count(void);
 /* Tuning knobs (no reference counterpart).  key 0 = structure of the 128->128 body convolution used by
  * models whose weights are loaded AFTER the call (0 = default; other values are experimental variants
  * kept for A/B measurements, all numerically equivalent up to summation order).  key 1 = timing-only
- * ablation mask of the persistent body kernel (diagnostics: outputs are wrong while it is non-zero). */
+ * ablation mask of the persistent body kernel (diagnostics: outputs are wrong while it is non-zero).
+ * key 2 = output-layer kernel, key 3 = start stagger quantum, key 4 = structure of the bf16 256->256 body
+ * convolution (2 = default; 0, 1, 3 = variants of the 32x32x16 form, 4 = the 16x16x32 form of
+ * conv3x3_body16.hip), read when a model is CREATED.  Python: DSEN2_TUNING="key=value,..." applies them at load. */
 int dsen2_set_tuning(int key, int value);
 
 /* ---- network object -------------------------------------------------------------------------
