@@ -190,8 +190,10 @@ def main():
                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK, 4), 'traffic': traffic,
                               'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
                               'traffic_source': traffic_src,
-                              'kernel': 'conv3x3_body_kernel (3x3x%dx%d, %s, persistent)' % (
-                                  FEAT, FEAT, 'bf16 MFMA 32x32x16' if bf else 'fp32 MFMA 32x32x2'),
+                              'kernel': '%s (3x3x%dx%d, %s, persistent)' % (
+                                  'conv3x3_body16_kernel' if bf and FEAT == 256 else 'conv3x3_body_kernel / conv3x3_bodyd_kernel',
+                                  FEAT, FEAT, ('bf16 MFMA 16x16x32, LDS-DMA staging' if FEAT == 256 else 'bf16 MFMA 32x32x16')
+                                  if bf else 'fp32 MFMA 32x32x2'),
                               'ms_per_launch': round(ms, 4), 'ms_relu': round(ms_relu, 4), 'ms_residual': round(ms_res, 4),
                               'flop_per_launch': flops}
         del a, r, o

@@ -1,23 +1,37 @@
-// conv3x3_body16.hip — bf16-operand F->F 3x3 'same' convolution built around v_mfma_f32_16x16x32_bf16.
+// conv3x3_body16.hip — bf16-operand 256->256 3x3 'same' convolution: v_mfma_f32_16x16x32_bf16 fed by LDS-DMA.
 //
-// Same persistent, software-pipelined structure as conv3x3_body.hip (one 8-wave workgroup per CU walking
-// (16x16 tile, 128-channel slab) items; 3-slot weight ring; double-buffered 64-channel input chunks; operand
-// fragments double buffered in registers), re-cut for the 16x16x32 shape with the WEIGHTS as the A operand:
+// Same persistent structure as conv3x3_body.hip (one 8-wave workgroup per CU walking (16x16 tile, 128-channel
+// slab) items, one step = (tap, 64 input channels), operand fragments double buffered in registers), with
+// three changes that the bf16 rate makes necessary (profiles/r01_ablation.md):
 //
-//   D[row = output channel][col = pixel] = sum_k W[row][k] * X[k][col]
+//   1. STAGING BY LDS-DMA.  Weight chunks (16 KiB per step) and input chunks go global -> LDS with
+//      `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction, LDS address = M0 + 16*lane, out-of-range lanes
+//      write zeros = the convolution's zero padding).  No staging VGPRs, no ds_write, no select.  The DMAs are
+//      issued from inline asm: hipcc neither tracks them in its waitcnt model (with the builtin it turns every
+//      counted lgkmcnt(N) of the fragment pipeline into lgkmcnt(0)) nor knows about the LDS they write, so the
+//      synchronisation is spelled out here:
+//        - vmcnt retires in ISSUE ORDER, all vector-memory operations of a wave together;
+//        - weight chunk c is issued at the START of step c-3 into ring slot c%4 (last read in step c-4, which
+//          ended with a barrier), retired by every wave's `s_waitcnt vmcnt(N)` at the END of step c-2 — N = the
+//          operations that wave issued after it, a compile-time count — followed by that step's barrier, and
+//          first read by the fragment prefetch at the end of step c-1;
+//        - the six rounds of an input chunk are issued at the start of taps 0-5 of the previous chunk's steps
+//          and are older than the weight DMA whose retirement is awaited at the end of tap 6;
+//        - a wait that assumes FEWER younger operations than there are is stricter, never weaker: the epilogue's
+//          loads and stores are not counted, so they drain within the next item's first step;
+//        - hipcc's own waits (for the epilogue's residual loads) assume fewer operations in flight than there
+//          are, which makes them stricter, never weaker.
+//   2. WEIGHTS ARE THE A OPERAND:  D[row = output channel][col = pixel].  A lane owns ONE pixel (col = lane & 15)
+//      and 4 output channels per accumulator (rows 4*(lane>>4) + r); the weight packing permutes the rows
+//      (pack_conv_weights_bf16_host, perm16) so that the two accumulators of a 32-channel pair hold 8
+//      CONSECUTIVE channels: the epilogue is one 16-byte bf16 store (or two 16-byte fp32 stores + residual
+//      loads) per lane, pair and pixel row — no cross-lane transposes, 8 stores per lane and item, not 64.
+//   3. CONFLICT-FREE FRAGMENT READS.  The input chunk lives in LDS as [channel group q: 8][pixel slot: 336][16 B]
+//      (the DMA's lane-linear destination makes any layout free): a pixel fragment is 16 consecutive pixels of
+//      one group = 16 consecutive 16-byte slots, and 336 = 0 mod 16 keeps the two groups of a ds_read_b128 lane
+//      group on disjoint banks.  The 2x16-pixel block of the 32x32x16 form is 2-way conflicted on any stride.
 //
-//   * a lane then owns ONE pixel (col = lane & 15) and 4 output channels per accumulator (rows 4*(lane>>4) + r).
-//     The weight packing permutes the rows (pack_conv_weights_bf16_host, perm16) so that the two accumulators
-//     of a 32-channel pair hold 8 CONSECUTIVE channels of that pixel: the epilogue is one 16-byte bf16 store
-//     (or two 16-byte fp32 stores + residual loads) per lane, pair and pixel row — no cross-lane transposes,
-//     8 stores per lane and item where the 32x32 form needs 64;
-//   * the pixel fragment is a 16-pixel row: with 40 words per halo pixel in LDS every ds_read_b128 of the
-//     loop is bank-conflict free (the 2x16 block of the 32x32x16 form is 2-way on any stride);
-//   * on random data the chip holds a higher clock on the 16x16x32 shape than on 32x32x16 at equal cycles per
-//     FLOP (MI355X_MICROARCH.md, DVFS give-back item 7).
-//
-// Per wave: 64 channels x 64 pixels = 4 x 4 accumulators; one step = (tap, 64 input channels) = 2 k-steps of
-// 16 MFMAs; 8 ds_read_b128 per k-step.
+// Per wave: 64 channels x 64 pixels = 4 x 4 accumulators, 2 k-steps of 16 MFMAs and 8 ds_read_b128 per step.
 #include <type_traits>
 
 #include "dsen2_internal.h"
@@ -35,19 +49,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KC = 32;                      // 32-bit words per pixel and step = 64 bf16 channels
 constexpr int NT = 128;                     // output channels per item
 constexpr int THREADS = 512;
-constexpr int PSTR = 40;                    // words per halo pixel in LDS: 16-pixel rows read conflict free
-constexpr int IN_WORDS = kHaloPix * PSTR;
-constexpr int WCH = KC * NT;                // words per weight chunk (16 KiB)
-constexpr int QPP = KC / 4;                 // 16-byte pieces per pixel and chunk
-constexpr int IN_PIECES = kHaloPix * QPP;
-constexpr int IN_ROUNDS = (IN_PIECES + THREADS - 1) / THREADS;      // 6
-constexpr int W_ROUNDS = (WCH / 4) / THREADS;                       // 2
-constexpr int NWBUF = 3;
+constexpr int QS = 336;                     // pixel slots per channel-group row (>= 324 halo pixels, = 0 mod 16)
+constexpr int IN_BYTES = 8 * QS * 16;       // one input chunk buffer: [8 groups][336 slots][16 B] = 43,008
+constexpr int IN_BLOCKS = 6;                // DMA rounds per chunk: 64 pixels each (the last one 16: slots 320-335)
+constexpr int WCH = KC * NT;                // words per weight chunk (16 KiB): [8 k-groups][128 rows][4 words]
+constexpr int NWBUF = 4;
 constexpr int KSTEPS = 2;                   // k = 32 channels per MFMA
 constexpr int RS = 4;                       // tile rows per wave
 constexpr int PB = 4, MB = 4;               // 16-pixel rows x 16-channel blocks per wave
-constexpr size_t LDS_BYTES = (size_t)(2 * IN_WORDS + NWBUF * WCH + 256) * 4;      // + the bias vector
-static_assert(IN_ROUNDS <= 8, "input round r is written mid tap r");
+constexpr size_t LDS_BYTES = (size_t)2 * IN_BYTES + (size_t)NWBUF * WCH * 4 + 256 * 4;      // + the bias vector
+static_assert(QS >= kHaloPix && QS % 16 == 0 && 64 * (IN_BLOCKS - 1) + 16 == QS, "input chunk geometry");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -55,22 +66,32 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 }  // namespace
 
 // CINW = words per input pixel (= F / 2).  ABL: timing-only ablation mask as in conv3x3_body.hip
 // (1 no stores, 2 no residual loads, 4 no weight stream, 8 no input stream, 16 no barriers).
-template <int CINW, int COUT, int EPI, int ABL>
+// PRE: accumulator pairs (0-2) whose residual values are fetched under the item's last step (2 spills registers).
+template <int CINW, int COUT, int EPI, int ABL, int PRE>
 __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvParams p, const int n_items) {
   constexpr int NCC = CINW / KC;
   constexpr int NCHUNK = NCC * 9;
   constexpr int NS = COUT / NT;
   static_assert(NCC % 2 == 0, "input double buffer parity");
+  constexpr int N_W = (ABL & 4) ? 0 : 2;                   // weight DMAs per wave and step
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const in_s = smem;                      // [2][324][PSTR]
-  float* const w_s = smem + 2 * IN_WORDS;        // [3][8 k-groups][128 rows][4 words]
-  float* const bias_s = w_s + NWBUF * WCH;       // [COUT]: the epilogue must not queue a vector-memory load
-                                                 // behind its own stores (vmcnt retires in issue order)
+  float* const in_s = smem;                            // [2][8][QS][4 words]
+  float* const w_s = smem + 2 * IN_BYTES / 4;          // [4][8 k-groups][128 rows][4 words]
+  float* const bias_s = w_s + NWBUF * WCH;             // [COUT]: the epilogue must not queue a vector-memory load
+                                                       // behind its own stores
+  const unsigned lds_in = (unsigned)(size_t)(__attribute__((address_space(3))) float*)in_s;
+  const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) float*)w_s;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,89 +110,79 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
   const int my_items = (n_items - lid + G - 1) / G;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const size_t img_pix = (size_t)p.h * p.w;
-
-  // ---- input staging (branch-free loads; zero padding selected in at the LDS write) ----
-  int g_off[IN_ROUNDS];
-  int s_off[IN_ROUNDS];
-  const float* stage_img = p.in;
-#pragma unroll
-  for (int r = 0; r < IN_ROUNDS; ++r) {
-    const int piece = r * THREADS + tid;
-    const int hp = piece / QPP, qq = piece - hp * QPP;
-    s_off[r] = piece < IN_PIECES ? hp * PSTR + qq * 4 : -1;
-  }
+  // ---- input stream: wave q fetches channel group q (8 channels = 16 B) of 64 halo pixels per DMA ----
+  unsigned in_voff[IN_BLOCKS];      // byte offset of (halo pixel 64*b + lane, group q) inside the image; out of range = zero
+  auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
   auto set_stage_item = [&](int item) {
     const int tile = item / NS;
     const int img = tile / tiles_per_img;
     const int trem = tile - img * tiles_per_img;
     const int tyi = trem / p.tiles_x;
     const int ty0 = tyi * kTile, tx0 = (trem - tyi * p.tiles_x) * kTile;
-    stage_img = p.in + (size_t)img * img_pix * CINW;
+    in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)img * img_pix * CINW, 0,
+                                                (unsigned)(img_pix * CINW * 4), 0x00020000);
 #pragma unroll
-    for (int r = 0; r < IN_ROUNDS; ++r) {
-      const int piece = r * THREADS + tid;
-      const int hp = piece / QPP, qq = piece - hp * QPP;
+    for (int b = 0; b < IN_BLOCKS; ++b) {
+      const int hp = 64 * b + lane;
       const int hy = hp / kHalo, hx = hp - hy * kHalo;
       const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-      const bool inb = piece < IN_PIECES && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
-      g_off[r] = inb ? (gy * p.w + gx) * CINW + qq * 4 : -1;
+      const bool inb = hp < kHaloPix && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
+      in_voff[b] = inb ? (unsigned)(((gy * p.w + gx) * CINW + wave * 4) * 4) : 0x80000000u;
     }
   };
-  auto load_in = [&](int r, int cc) -> f32x4 {
-    return *reinterpret_cast<const f32x4*>(stage_img + (g_off[r] >= 0 ? g_off[r] : 0) + cc * KC);
-  };
-  auto store_in = [&](float* buf, int r, f32x4 t) {
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = g_off[r] >= 0 ? t[e] : 0.f;
-    if (s_off[r] >= 0) *reinterpret_cast<f32x4*>(buf + s_off[r]) = v;
+  // round b of input chunk cc into buffer `buf`
+  auto issue_in = [&](int buf, int b, int cc) {
+    const unsigned m0v = lds_in + buf * IN_BYTES + (wave * QS + 64 * b) * 16;
+    const unsigned so = cc * (KC * 4);
+    if (b < IN_BLOCKS - 1) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                   ::"s"(m0v), "v"(in_voff[b]), "s"(in_rsrc), "s"(so) : "memory");
+    } else if (lane < 16) {          // slots 320-335 only: the next group's row starts at 336
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                   ::"s"(m0v), "v"(in_voff[b]), "s"(in_rsrc), "s"(so) : "memory");
+    }
   };
 
-  // ---- weight stream: chunk c loaded (global -> VGPR) in step c-3, written to ring slot c%3 in step c-2,
-  //      first read by the fragment prefetch at the end of step c-1 ----
-  int wl_item = lid;
+  // ---- weight stream: 16 waves-instructions of 1 KiB per chunk, two per wave ----
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (unsigned)(NS * NCHUNK * WCH * 4), 0x00020000);
+  const unsigned w_voff = lane * 16;
+  int wl_item = lid;           // item / chunk the next issued DMA belongs to
   int wl_chunk = 0;
   int st_slot = 0;
-  auto load_w = [&](f32x4 (&wr)[W_ROUNDS]) {
-    const float* src = p.wpk + ((size_t)(wl_item % NS) * NCHUNK + wl_chunk) * WCH + tid * 4;
-#pragma unroll
-    for (int r = 0; r < W_ROUNDS; ++r) wr[r] = *reinterpret_cast<const f32x4*>(src + r * THREADS * 4);
+  auto issue_w = [&]() {
+    const unsigned so = (unsigned)(((wl_item % NS) * NCHUNK + wl_chunk) * (WCH * 4) + wave * 1024);
+    const unsigned l0 = lds_w + st_slot * (WCH * 4) + wave * 1024;
+    asm volatile(
+        "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %5 offen lds"
+        ::"s"(l0), "s"(l0 + 8192u), "v"(w_voff), "s"(w_rsrc), "s"(so), "s"(so + 8192u)
+        : "memory");
     if (++wl_chunk == NCHUNK) {
       wl_chunk = 0;
       wl_item = wl_item + G < n_items ? wl_item + G : lid;
     }
-  };
-  auto store_w = [&](const f32x4 (&wr)[W_ROUNDS]) {
-    float* dst = w_s + st_slot * WCH + tid * 4;
-#pragma unroll
-    for (int r = 0; r < W_ROUNDS; ++r) *reinterpret_cast<f32x4*>(dst + r * THREADS * 4) = wr[r];
     st_slot = st_slot == NWBUF - 1 ? 0 : st_slot + 1;
   };
 
   // ---- per-lane operand addresses (words) ----
-  // B operand (pixels): lane -> pixel column l15 of a 16-pixel row, channels 8*q4 .. +7 of the k-step
+  // B operand (pixels): lane -> pixel column l15 of a 16-pixel row, channel group 4*s + q4 of the chunk
   // A operand (weights): [k-group = 4*s + q4][row = wn*64 + 16*mb + l15][4 words]
-  const int x_lane = ((RS * wp) * kHalo + l15) * PSTR + 4 * q4;
+  const int x_lane = (q4 * QS + (RS * wp) * kHalo + l15) * 4;
   const int w_lane = (q4 * NT + wn * 64 + l15) * 4;
 
-  f32x4 wr[W_ROUNDS];
-  f32x4 ir;
+  // ---- prologue: first item's input chunk 0, weight chunks 0-2 ----
   set_stage_item(lid);
-  {
-    f32x4 ir0[IN_ROUNDS];
+  if constexpr (!(ABL & 8)) {
 #pragma unroll
-    for (int r = 0; r < IN_ROUNDS; ++r) ir0[r] = load_in(r, 0);
-    f32x4 w0[W_ROUNDS], w1[W_ROUNDS];
-    load_w(w0);
-    load_w(w1);
-    store_w(w0);
-    store_w(w1);
-#pragma unroll
-    for (int r = 0; r < IN_ROUNDS; ++r) store_in(in_s, r, ir0[r]);
-    load_w(wr);
-    ir = load_in(0, 1);
-    if (tid < COUT) bias_s[tid] = p.bias[tid];
+    for (int b = 0; b < IN_BLOCKS; ++b) issue_in(0, b, 0);
   }
+  if constexpr (!(ABL & 4)) {
+    issue_w();
+    issue_w();
+    issue_w();
+  }
+  if (tid < COUT) bias_s[tid] = p.bias[tid];
+  wait_vmcnt<0>();
   __syncthreads();
 
   f32x4 w_cur[MB], x_cur[PB], w_nxt[MB], x_nxt[PB];
@@ -179,63 +190,74 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
   auto read_frags = [&](f32x4 (&wf)[MB], f32x4 (&xf)[PB], const float* ib, const float* wb, int tap, int s) {
     const int dy = tap / 3, dx = tap - dy * 3;
     const float* wp_ = wb + w_lane + (4 * s * NT) * 4;
-    const float* xp_ = ib + x_lane + (dy * kHalo + dx) * PSTR + 16 * s;
+    const float* xp_ = ib + x_lane + (4 * s * QS + dy * kHalo + dx) * 4;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) wf[mb] = *reinterpret_cast<const f32x4*>(wp_ + mb * 16 * 4);
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) xf[pb] = *reinterpret_cast<const f32x4*>(xp_ + pb * kHalo * PSTR);
+    for (int pb = 0; pb < PB; ++pb) xf[pb] = *reinterpret_cast<const f32x4*>(xp_ + pb * kHalo * 4);
   };
   read_frags(w_cur, x_cur, in_s, w_s, 0, 0);
 
-  // The item loop is ROTATED: an iteration first writes out the PREVIOUS item's accumulators, then runs this
-  // item's 36 steps (one extra iteration writes the last item; the first one stores to out-of-range offsets,
-  // which the buffer unit drops).  The staging loads issued in an item's last step are consumed half a step into
-  // the next item, i.e. right after the epilogue's stores, and vmcnt retires in issue order: with every path
-  // into the first step's wait passing the same stores, hipcc emits vmcnt(#stores + k) there and the stores
-  // retire behind the next item's MFMAs; with the epilogue at the loop's tail the wait merges with the
-  // prologue's store-free path, becomes vmcnt(k) and drains the stores at the head of every item.  For the
-  // same reason the first input chunk (cc = 0) is its own copy of the step code.
-  auto run = [&](auto mid_c) {
-  constexpr int MIDS = decltype(mid_c)::value;
+  // The item loop is ROTATED: an iteration first writes out the PREVIOUS item's accumulators, then runs this item's
+  // 36 steps (one extra iteration writes the last item; the first one stores to out-of-range offsets, which the
+  // buffer unit drops).  Every path into an item's first step then passes the same epilogue, so its vector-memory
+  // operations could be counted by that step's wait; the first input chunk (cc = 0) is its own copy of the step
+  // code for the same reason.  (Counting them measured no gain — see the wait below — but the shape is kept: it
+  // costs nothing and keeps that option one template argument away.)
   f32x4 acc[MB][PB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) acc[mb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // residual values of the first PRE accumulator pairs, fetched at the head of an item's last step
+  constexpr int kPre = EPI == kEpiResidual && !(ABL & 2) ? PRE : 0;
+  f32x4 resv[kPre ? kPre : 1][PB][2];
+#pragma unroll
+  for (int pr = 0; pr < (kPre ? kPre : 1); ++pr)
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) resv[pr][pb][0] = resv[pr][pb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // geometry of one item's output: descriptor of its image, the lane's element offset, validity
+  struct OutGeom { int img; unsigned lane_eoff; int ey; bool col_ok; int ch8; };
+  auto out_geom = [&](int item, bool valid) -> OutGeom {
+    const int tile = item / NS, slab = item - tile * NS;
+    const int img = tile / tiles_per_img;
+    const int trem = tile - img * tiles_per_img;
+    const int tyi = trem / p.tiles_x;
+    const int ty0 = tyi * kTile, tx0 = (trem - tyi * p.tiles_x) * kTile;
+    const int ch8 = slab * NT + wn * 64 + 8 * q4;
+    const int ex = tx0 + l15, ey = ty0 + RS * wp;
+    return OutGeom{img, (unsigned)((ey * p.w + ex) * COUT + ch8), ey, valid && ex < p.w, ch8};
+  };
+  auto aux_desc = [&](int img) {
+    return __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.aux) + (EPI == kEpiResidual ? (size_t)img * img_pix * COUT : 0), 0,
+        EPI == kEpiResidual ? (unsigned)(img_pix * COUT * 4) : 0, 0x00020000);
+  };
+  // elements; 0x20000000 is out of range once scaled to bytes (x2, x4)
+  auto elem_off = [&](const OutGeom& g, int pr, int pb) -> unsigned {
+    return g.col_ok && g.ey + pb < p.h ? g.lane_eoff + (unsigned)(pb * p.w * COUT + pr * 32) : 0x20000000u;
+  };
 
   for (int it = 0; it <= my_items; ++it) {
     // ---- epilogue of item it-1: lane = pixel (ex, ey + pb), 8 consecutive channels ch8 + 32*pr per pair ----
     {
-      const bool valid = it > 0;
-      const int item = valid ? lid + (it - 1) * G : lid;
-      const int tile = item / NS, slab = item - tile * NS;
-      const int img = tile / tiles_per_img;
-      const int trem = tile - img * tiles_per_img;
-      const int tyi = trem / p.tiles_x;
-      const int ty0 = tyi * kTile, tx0 = (trem - tyi * p.tiles_x) * kTile;
+      const OutGeom g = out_geom(it > 0 ? lid + (it - 1) * G : lid, it > 0);
       // one buffer descriptor per image; pixels outside a ragged tile get an out-of-range offset, not a branch
       constexpr unsigned OB = EPI == kEpiRelu ? 2u : 4u;          // bytes per element of p.out
-      const int ch8 = slab * NT + wn * 64 + 8 * q4;
-      const auto aux_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(p.aux) + (EPI == kEpiResidual ? (size_t)img * img_pix * COUT : 0), 0,
-          EPI == kEpiResidual ? (unsigned)(img_pix * COUT * 4) : 0, 0x00020000);
+      const auto aux_rsrc = aux_desc(g.img);
       const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<char*>(p.out) + (size_t)img * img_pix * COUT * OB, 0, (unsigned)(img_pix * COUT * OB), 0x00020000);
+          reinterpret_cast<char*>(p.out) + (size_t)g.img * img_pix * COUT * OB, 0, (unsigned)(img_pix * COUT * OB), 0x00020000);
       const auto out2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<char*>(p.out2) + (EPI == kEpiResidual ? (size_t)img * img_pix * COUT * 2 : 0), 0,
+          reinterpret_cast<char*>(p.out2) + (EPI == kEpiResidual ? (size_t)g.img * img_pix * COUT * 2 : 0), 0,
           EPI == kEpiResidual ? (unsigned)(img_pix * COUT * 2) : 0, 0x00020000);
-      const int ex = tx0 + l15, ey = ty0 + RS * wp;
-      const unsigned lane_eoff = (unsigned)((ey * p.w + ex) * COUT + ch8);              // elements
-      const bool col_ok = valid && ex < p.w;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + ch8 + 32 * pr);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + ch8 + 32 * pr + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + g.ch8 + 32 * pr);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + g.ch8 + 32 * pr + 4);
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
           f32x4 v0 = acc[2 * pr][pb] + b0, v1 = acc[2 * pr + 1][pb] + b1;
-          // elements; 0x20000000 is out of range once scaled to bytes (x2, x4)
-          const unsigned eo = col_ok && ey + pb < p.h ? lane_eoff + (unsigned)(pb * p.w * COUT + pr * 32) : 0x20000000u;
+          const unsigned eo = elem_off(g, pr, pb);
           if constexpr (EPI == kEpiRelu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -250,8 +272,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
           } else {
             f32x4 r0 = {1.f, 1.f, 1.f, 1.f}, r1 = r0;
             if constexpr (!(ABL & 2)) {
-              r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, eo * 4u, 0, 0));
-              r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, eo * 4u + 16u, 0, 0));
+              if (pr < kPre) {
+                r0 = resv[pr][pb][0];
+                r1 = resv[pr][pb][1];
+              } else {
+                r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, eo * 4u, 0, 0));
+                r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, eo * 4u + 16u, 0, 0));
+              }
             }
             v0 = r0 + v0 * p.res_scale;       // -ffp-contract=off: two roundings, as keras
             v1 = r1 + v1 * p.res_scale;
@@ -277,16 +304,21 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
       for (int pb = 0; pb < PB; ++pb) acc[mb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto do_cc = [&](const int cc, auto first_c) {
-      (void)first_c;     // distinct instantiation = distinct copy of the step code for cc == 0
-      const float* const ib = in_s + (cc & 1) * IN_WORDS;
-      float* const ib_next = in_s + ((cc + 1) & 1) * IN_WORDS;
+      (void)first_c;      // cc == 0 is its own copy of the step code (kept: hipcc schedules it around the epilogue)
+      const float* const ib = in_s + (cc & 1) * (IN_BYTES / 4);
+      const float* const ib_next = in_s + ((cc + 1) & 1) * (IN_BYTES / 4);
+      // what is staged into ib_next during this cc: (this item, cc+1), or on the last cc the NEXT item's chunk 0
+      // (on the very last item: its own chunk 0 again, which nobody reads)
       const bool last_cc = cc == NCC - 1;
       const int in_cc = last_cc ? 0 : cc + 1;
+      if (last_cc && have_next_item) set_stage_item(item + G);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const float* const wb = w_s + mf_slot * WCH;
         const int nx_slot = mf_slot == NWBUF - 1 ? 0 : mf_slot + 1;
         const float* const wb_nx = w_s + nx_slot * WCH;
+        constexpr int kNoIn = (ABL & 8) ? 1 : 0;
+        const int n_in = (tap < IN_BLOCKS && !kNoIn) ? 1 : 0;     // folds: tap is an unrolled constant
 
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
@@ -297,18 +329,24 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
           } else {
             read_frags(w_nxt, x_nxt, ib_next, wb_nx, 0, 0);
           }
-          if (s == MIDS) {
-            if constexpr (!(ABL & 4)) store_w(wr);
-            if constexpr (!(ABL & 8))
-              if (tap < IN_ROUNDS) store_in(ib_next, tap < IN_ROUNDS ? tap : 0, ir);
-            if constexpr (!(ABL & 4)) load_w(wr);
-            if constexpr (!(ABL & 8)) {
-              if (tap + 1 < IN_ROUNDS) {
-                ir = load_in(tap + 1 < IN_ROUNDS ? tap + 1 : 0, in_cc);
-              } else if (tap == 8) {
-                const int nn = cc + 2;
-                if (nn == NCC && have_next_item) set_stage_item(item + G);
-                ir = load_in(0, nn < NCC ? nn : nn - NCC);
+          if (s == 0) {
+            // this step's DMAs: input round first, then the weight chunk three steps ahead
+            if (n_in) issue_in((cc + 1) & 1, tap < IN_BLOCKS ? tap : 0, in_cc);
+            if constexpr (!(ABL & 4)) issue_w();
+            if constexpr (kPre > 0) {
+              // the item's last step: its residual values, younger than the step's DMAs, land under its 32 MFMAs
+              // (the wait that ends the step then covers them too, which is when they are needed)
+              if (tap == 8 && last_cc) {
+                const OutGeom g = out_geom(item, true);
+                const auto aux_rsrc = aux_desc(g.img);
+#pragma unroll
+                for (int pr = 0; pr < kPre; ++pr)
+#pragma unroll
+                  for (int pb = 0; pb < PB; ++pb) {
+                    const unsigned eo = elem_off(g, pr, pb);
+                    resv[pr][pb][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, eo * 4u, 0, 0));
+                    resv[pr][pb][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, eo * 4u + 16u, 0, 0));
+                  }
               }
             }
           }
@@ -327,6 +365,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
         }
         mf_slot = nx_slot;
         __builtin_amdgcn_sched_barrier(0);
+        // retire the weight chunk issued at the start of the PREVIOUS step (and everything older): what this wave
+        // issued after it is AT LEAST this step's input round and weight chunk.  (After an epilogue its loads and
+        // stores are younger too; counting them — vmcnt(N_W + 1 + 8) for the ReLU form — measured no faster, so the
+        // simple count stays: the stores of an item drain within its successor's first step.)
+        if (n_in) wait_vmcnt<N_W + 1>(); else wait_vmcnt<N_W>();
         if constexpr (!(ABL & 16)) __syncthreads();
       }
     };
@@ -334,14 +377,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
 #pragma unroll 1
     for (int cc = 1; cc < NCC; ++cc) do_cc(cc, std::false_type{});
   }
-  };   // run
-  // (a wave-group stagger of the staging slot, as in conv3x3_body.hip, needs two copies of the loop: 33 spills)
-  run(std::integral_constant<int, 0>{});
+  wait_vmcnt<0>();       // no DMA may still be writing this workgroup's LDS when it is released
 }
 
-template <int CINW, int COUT, int EPI, int ABL = 0>
+template <int CINW, int COUT, int EPI, int ABL = 0, int PRE = 0>
 static hipError_t launch_body16_one(const ConvParams& p, hipStream_t stream) {
-  auto kern = conv3x3_body16_kernel<CINW, COUT, EPI, ABL>;
+  auto kern = conv3x3_body16_kernel<CINW, COUT, EPI, ABL, PRE>;
   static bool attr_set[64] = {};
   static int cus[64] = {};
   int dev = 0;
@@ -364,9 +405,9 @@ static hipError_t launch_body16_one(const ConvParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, hipStream_t stream) {
+hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, int sub, hipStream_t stream) {
   if (epilogue == kEpiResidual && !p.out2) return hipErrorInvalidValue;
-  if (feat != 256) return hipErrorInvalidValue;     // F = 128 (two input chunks) compiles to 58 spills: not offered
+  if (feat != 256) return hipErrorInvalidValue;
   if (g_body_ablate != 0) {
 #define DSEN2_ABL(M)                                                                     \
   if (g_body_ablate == M)                                                                \
@@ -376,8 +417,11 @@ hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, hi
 #undef DSEN2_ABL
     return hipErrorInvalidValue;
   }
-  return epilogue == kEpiRelu ? launch_body16_one<128, 256, kEpiRelu>(p, stream)
-                              : launch_body16_one<128, 256, kEpiResidual>(p, stream);
+  if (epilogue == kEpiRelu) return launch_body16_one<128, 256, kEpiRelu>(p, stream);
+  // sub: 0 = first accumulator pair's residual values prefetched (default), 1 = none, 2 = both pairs (12 spills)
+  if (sub == 1) return launch_body16_one<128, 256, kEpiResidual, 0, 0>(p, stream);
+  if (sub == 2) return launch_body16_one<128, 256, kEpiResidual, 0, 2>(p, stream);
+  return launch_body16_one<128, 256, kEpiResidual, 0, 1>(p, stream);
 }
 
 }  // namespace dsen2

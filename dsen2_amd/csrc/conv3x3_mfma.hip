@@ -315,8 +315,10 @@ static inline uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
-int g_bf16_variant = 2;   // tuning key 4: 2 = deferred-epilogue kernel (falls back to 0); 0 = one 8-wave workgroup per CU,
-                          // 64-channel steps; 1 = two 4-wave workgroups, 32-channel steps
+// tuning key 4 (256->256 bf16 body convolution): 4 = 16x16x32 MFMA fed by LDS-DMA (conv3x3_body16.hip; 5, 6 = its
+// residual-prefetch sub-variants); the 32x32x16 forms stay for A/B: 0 = one 8-wave workgroup per CU, 64-channel steps;
+// 1 = two 4-wave workgroups, 32-channel steps; 2 = conv-A with wave-group stagger + conv-B deferred; 3 = deferred both
+int g_bf16_variant = 4;
 
 void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch, bool perm16, uint16_t* dst) {
   // [slab][cc (chunk_ch channels)][tap][g (8 channels)][o (128)][j (8)]: one (slab, cc, tap) chunk is the LDS image

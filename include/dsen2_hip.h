@@ -44,8 +44,8 @@ int dsen2_device_count(void);
  * kept for A/B measurements, all numerically equivalent up to summation order).  key 1 = timing-only
  * ablation mask of the persistent body kernel (diagnostics: outputs are wrong while it is non-zero).
  * key 2 = output-layer kernel, key 3 = start stagger quantum, key 4 = structure of the bf16 256->256 body
- * convolution (2 = default; 0, 1, 3 = variants of the 32x32x16 form, 4 = the 16x16x32 form of
- * conv3x3_body16.hip), read when a model is CREATED.  Python: DSEN2_TUNING="key=value,..." applies them at load. */
+ * convolution (4 = default: 16x16x32 MFMA fed by LDS-DMA, conv3x3_body16.hip; 5, 6 = its residual-prefetch
+ * sub-variants; 0-3 = the 32x32x16 forms of conv3x3_body.hip / conv3x3_bodyd.hip), read when a model is CREATED.  Python: DSEN2_TUNING="key=value,..." applies them at load. */
 int dsen2_set_tuning(int key, int value);
 
 /* ---- network object -------------------------------------------------------------------------
@@ -54,7 +54,7 @@ int dsen2_set_tuning(int key, int value);
  *   The output has the channel count of the last input and that input is added back (:35-41).
  *   feature_size must be a multiple of 128 (reference uses 128 and 256, testing/supres.py:56,59).
  *   precision: 0 = fp32 everywhere (exact-f32 MFMA); 1 = bf16 operands for the residual-block convolutions
- *   (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 residual stream, fp32 first and last convolution.
+ *   (v_mfma_f32_16x16x32_bf16 at F = 256, v_mfma_f32_32x32x16_bf16 at F = 128), fp32 accumulation, fp32 residual stream, fp32 first and last convolution.
  */
 int dsen2_model_create(dsen2_model **out, int c10, int c20, int c60, int num_layers, int feature_size,
                        int precision);

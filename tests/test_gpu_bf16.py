@@ -84,14 +84,14 @@ def test_bf16_network_ragged_and_variant():
     scale = float(np.sqrt(np.mean(ref ** 2)))
     outs = []
     try:
-        for v in (0, 1, 2, 3, 4):       # every structure of the 256->256 bf16 body convolution (tuning key 4)
+        for v in (0, 1, 2, 3, 4, 5, 6):       # every structure of the 256->256 bf16 body convolution (tuning key 4)
             _lib.call('dsen2_set_tuning', 4, v)
             m = s2model(((4, None, None), (6, None, None)), num_layers=3, feature_size=256, precision='bf16')
             m.set_weights_flat(flat)
             outs.append(m.predict(xs))
             assert do.rmse(outs[-1], ref) / scale < 5e-3
     finally:
-        _lib.call('dsen2_set_tuning', 4, 2)      # the library default
+        _lib.call('dsen2_set_tuning', 4, 4)      # the library default
     # same products, same fp32 accumulation order per output element? (64- vs 32-channel steps differ only in
     # where the k loop is cut, not in its order) -> the two structures agree to fp32 rounding of the bf16 copies
     for o in outs[1:]:

@@ -12,7 +12,7 @@ ms = {}
 for v in VARIANTS:
     _lib.call('dsen2_set_tuning', 4, v)
     ms[v] = s2model(((4, None, None), (6, None, None)), num_layers=2, feature_size=F, precision='bf16'); ms[v].set_weights_flat(flat)
-_lib.call('dsen2_set_tuning', 4, 0)
+_lib.call('dsen2_set_tuning', 4, 4)
 a = torch.randn((B, H, H, F), device='cuda').to(torch.bfloat16); r = torch.randn((B, H, H, F), device='cuda')
 outs = {}
 for v in VARIANTS:
