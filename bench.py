@@ -176,9 +176,12 @@ def main():
             o = torch.empty((args.batch * 3 // 2 + 1, H, W, FEAT), dtype=torch.float32, device=dev)   # fp32 out + bf16 copy
         else:
             o = torch.empty_like(a)
+        # (1) the launch duration inside the running network: HIP events on the launch stream around the 2d body
+        #     convolutions of `steps` more forward passes on the bench inputs (what rocprofv3 --kernel-trace averages)
+        ms = model.time_body_in_forward(xs, out=outs[0], iters=args.steps)
+        # (2) each epilogue alone, back to back, on dense random operands (no ReLU zeros: the chip clocks lower)
         ms_relu = model.time_body_conv(1, a, None, o, iters=10)          # conv-A (+bias+ReLU)
         ms_res = model.time_body_conv(2, a, r, o, iters=10)              # conv-B (+bias, *0.1, +residual)
-        ms = 0.5 * (ms_relu + ms_res)
         flops = pix * FLOP_PER_PIXEL_BODY
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, 'profiles', 'body_conv_traffic.json')
@@ -191,10 +194,11 @@ def main():
                               'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
                               'traffic_source': traffic_src,
                               'kernel': '%s (3x3x%dx%d, %s, persistent)' % (
-                                  'conv3x3_body16_kernel' if bf and FEAT == 256 else 'conv3x3_body_kernel / conv3x3_bodyd_kernel',
+                                  'conv3x3_body16_kernel' if bf and FEAT == 256 else 'conv3x3_body_kernel' if bf else 'conv3x3_body32_kernel',
                                   FEAT, FEAT, ('bf16 MFMA 16x16x32, LDS-DMA staging' if FEAT == 256 else 'bf16 MFMA 32x32x16')
-                                  if bf else 'fp32 MFMA 32x32x2'),
-                              'ms_per_launch': round(ms, 4), 'ms_relu': round(ms_relu, 4), 'ms_residual': round(ms_res, 4),
+                                  if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging'),
+                              'ms_per_launch': round(ms, 4), 'ms_per_launch_source': 'HIP events around the %d body-conv launches of %d forward passes' % (2 * NUM_LAYERS, args.steps),
+                              'ms_relu_randn': round(ms_relu, 4), 'ms_residual_randn': round(ms_res, 4),
                               'flop_per_launch': flops}
         del a, r, o
 

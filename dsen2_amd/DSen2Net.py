@@ -93,6 +93,21 @@ class S2Model(object):
                       _ptr(ws), ws.numel(), _stream_ptr(self.device))
         return out
 
+    def time_body_in_forward(self, xs, out=None, iters=10):
+        """Mean duration (ms) of ONE residual-block convolution launch inside `iters` full forward passes on `xs`
+        (HIP events on the launch stream around the 2*num_layers body convolutions of each pass): the duration the
+        kernel has in the running network — bench.py's roofline measurement."""
+        n, _, h, w = xs[0].shape
+        if out is None:
+            out = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=self.device)
+        ws = self._get_workspace(self.workspace_bytes(n, h, w))
+        ms = ctypes.c_float(0)
+        with torch.cuda.device(self.device):
+            _lib.call('dsen2_model_forward_timed', self._handle, _ptr(xs[0]), _ptr(xs[1]),
+                      _ptr(xs[2]) if len(xs) == 3 else ctypes.c_void_p(0), _ptr(out), n, h, w,
+                      _ptr(ws), ws.numel(), _stream_ptr(self.device), int(iters), ctypes.byref(ms))
+        return ms.value
+
     def batch_limit(self, h, w):
         per = self.workspace_bytes(1, h, w)
         return max(1, int(self.max_workspace_bytes // per))

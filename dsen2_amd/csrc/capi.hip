@@ -63,7 +63,7 @@ const char* dsen2_last_error(void) { return g_err; }
 
 int dsen2_set_tuning(int key, int value) {
   if (key == 0) {
-    if (value < 0 || value > 10 || value == 7) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
+    if (value < 0 || value > 14 || value == 7) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
     g_body_variant = value;
     return DSEN2_OK;
   }
@@ -211,8 +211,11 @@ static ConvParams make_params(const float* in, const float* wpk, const float* bi
   return p;
 }
 
-int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
-                        int h, int w, void* workspace, size_t workspace_bytes, void* stream_) {
+// ev_body0 / ev_body1 (optional): recorded on the stream right before the first and right after the last
+// residual-block convolution
+static int forward_impl(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
+                        int h, int w, void* workspace, size_t workspace_bytes, void* stream_, hipEvent_t ev_body0,
+                        hipEvent_t ev_body1) {
   if (!m || !x10 || !x20 || !out || !workspace) return fail(DSEN2_ERR_INVALID, "NULL argument");
   if ((m->c60 > 0) != (x60 != nullptr)) return fail(DSEN2_ERR_INVALID, "x60 must be given iff the model has a 60 m input");
   if (!m->loaded) return fail(DSEN2_ERR_NO_WEIGHTS, "dsen2_model_load_weights has not been called");
@@ -235,12 +238,14 @@ int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, cons
     const Layer& L = m->layers[li++];            // DSen2Net.py:29
     HIP_TRY(launch_conv3x3(make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f), L.geom, L.epilogue, stream));
   }
+  if (ev_body0 && m->precision != 1) HIP_TRY(hipEventRecord(ev_body0, stream));
   if (m->precision == 1) {
     // bf16 operands / fp32 accumulate and residual stream: `a` stays fp32, `t` and the operand copy `abf` of
     // `a` are bf16 (each half the size of an fp32 activation, together they fit the fp32 path's `t`)
     void* abf = t;
     void* tbf = reinterpret_cast<char*>(t) + align_up(pix * m->feat / 2) * sizeof(float);
     HIP_TRY(launch_f32_to_bf16(a, abf, pix * m->feat, stream));
+    if (ev_body0) HIP_TRY(hipEventRecord(ev_body0, stream));
     for (int i = 0; i < m->num_layers; ++i) {
       const Layer& LA = m->layers[li++];
       ConvParams pa = make_params(reinterpret_cast<const float*>(abf), P + LA.w_off, P + LA.b_off, nullptr,
@@ -259,11 +264,41 @@ int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, cons
     // in place on the residual stream: every workgroup reads aux and writes out at its own pixels only
     HIP_TRY(launch_conv3x3(make_params(t, P + LB.w_off, P + LB.b_off, a, a, n, h, w, 0, 0.1f), LB.geom, LB.epilogue, stream));
   }
+  if (ev_body1) HIP_TRY(hipEventRecord(ev_body1, stream));
   {
     const Layer& L = m->layers[li++];            // DSen2Net.py:35,38,41
     HIP_TRY(launch_conv3x3(make_params(a, P + L.w_off, P + L.b_off, skip, out, n, h, w, m->cout, 0.f), L.geom, L.epilogue, stream));
   }
   return DSEN2_OK;
+}
+
+int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
+                        int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+  return forward_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+int dsen2_model_forward_timed(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
+                              int h, int w, void* workspace, size_t workspace_bytes, void* stream, int iters,
+                              float* body_ms_per_launch) {
+  if (iters <= 0 || iters > 4096 || !body_ms_per_launch) return fail(DSEN2_ERR_INVALID, "bad iters / NULL result");
+  if (!m || m->num_layers <= 0) return fail(DSEN2_ERR_INVALID, "model has no residual blocks");
+  std::vector<hipEvent_t> ev(2 * (size_t)iters, nullptr);
+  int rc = DSEN2_OK;
+  for (size_t i = 0; i < ev.size() && rc == DSEN2_OK; ++i)
+    if (hipEventCreate(&ev[i]) != hipSuccess) rc = fail(DSEN2_ERR_HIP, "hipEventCreate failed");
+  for (int i = 0; i < iters && rc == DSEN2_OK; ++i)
+    rc = forward_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, ev[2 * i], ev[2 * i + 1]);
+  double total = 0.0;
+  if (rc == DSEN2_OK && hipEventSynchronize(ev.back()) != hipSuccess) rc = fail(DSEN2_ERR_HIP, "hipEventSynchronize failed");
+  for (int i = 0; i < iters && rc == DSEN2_OK; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = fail(DSEN2_ERR_HIP, "hipEventElapsedTime failed");
+    total += ms;
+  }
+  for (hipEvent_t e : ev)
+    if (e) (void)hipEventDestroy(e);
+  if (rc == DSEN2_OK) *body_ms_per_launch = (float)(total / iters / (2.0 * m->num_layers));
+  return rc;
 }
 
 int dsen2_conv3x3_nhwc(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,

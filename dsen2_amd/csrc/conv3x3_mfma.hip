@@ -268,9 +268,11 @@ static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
 }
 
 int g_out_variant = 1;    // 1 = 16x16x4 output-layer kernel (conv3x3_out.hip); 0 = padded 32-wide block of this file
-int g_body_variant = 8;   // tuning knob (dsen2_set_tuning): structure used for F->F body convs packed from now on
-                          // 8 = persistent kernel with deferred epilogue (conv3x3_bodyd.hip; falls back to 4 where it does
-                          // not apply); 4 = persistent kernel (conv3x3_body.hip); 0 = one tile per workgroup; 1-3, 5, 6 = A/B variants
+// tuning key 0 (dsen2_set_tuning): structure used for the F->F fp32 body convolutions packed from now on
+//   14 = DMA-fed kernel, deferred epilogue + wave-group stagger (conv3x3_body32.hip; 11-13 = its sub-variants 0-2);
+//   8 = register-staged persistent kernels: conv-A staggered (9), conv-B deferred (conv3x3_bodyd.hip; 10 = deferred both);
+//   4 = persistent kernel (conv3x3_body.hip); 0 = one tile per workgroup; 1-3, 5, 6 = earlier A/B variants
+int g_body_variant = 14;
 
 bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
   if (cin <= 0 || cout <= 0) return false;
@@ -287,7 +289,10 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
     *g = PackGeom{(v == 1 || v == 2 || v == 5) ? 16 : 32, 128, cin, cout, v};   // 8, 9, 10 share variant 4's packing
     return true;
   }
-  if (cin == 256 && cout == 256) { *g = PackGeom{32, 128, cin, cout, g_body_variant >= 4 ? 4 : 0}; return true; }   // no deferred form (8 chunks)
+  if (cin == 256 && cout == 256) {   // no deferred form (8 chunks): persistent kernel, or the DMA-fed one (11-14)
+    *g = PackGeom{32, 128, cin, cout, g_body_variant >= 11 ? g_body_variant : g_body_variant >= 4 ? 4 : 0};
+    return true;
+  }
   return false;
 }
 
@@ -339,6 +344,11 @@ void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, hipStream_t stream) {
   const int cin_pad = geom.cin_pad, cout_pad = geom.cout_pad;
   if (geom.variant == 7 && epilogue == kEpiSkipNCHW) return launch_conv3x3_out(p, cin_pad, stream);
+  // 11-14: the DMA-fed kernel (conv3x3_body32.hip) and its sub-variants; tensors it cannot address fall through
+  if (geom.variant >= 11 && geom.variant <= 14 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW) {
+    if (body32_supports(p, cout_pad)) return launch_conv3x3_body32(p, cin_pad, epilogue, geom.variant - 11, stream);
+    return launch_conv3x3_body(p, cin_pad, epilogue, 4, stream);
+  }
   // default (8): conv-B (residual) on the deferred-epilogue kernel; conv-A (ReLU) on the persistent kernel with the
   // wave-group stagger (variant 9) — measured best of {4, 8, 9} for each epilogue (tools/ab_body_conv.py)
   if (geom.variant == 8 && cin_pad == 128 && cout_pad == 128 && epilogue == kEpiResidual && g_body_ablate == 0 &&

@@ -52,6 +52,9 @@ extern int g_body_ablate;   // timing-only ablation mask of the persistent body 
 // deferred-epilogue persistent kernel (conv3x3_bodyd.hip): fp32 F=128 and bf16 F=256 only, tensors < 4 GiB
 bool bodyd_supports(const ConvParams& p, int cout);
 hipError_t launch_conv3x3_bodyd(const ConvParams& p, int feat, int epilogue, bool bf16, hipStream_t stream);
+// DMA-fed fp32 kernel (conv3x3_body32.hip): F = 128 or 256, images < 2 GiB; weights packed with KC=32, NT=128
+bool body32_supports(const ConvParams& p, int cout);
+hipError_t launch_conv3x3_body32(const ConvParams& p, int feat, int epilogue, int sub, hipStream_t stream);
 // bf16-operand form of the persistent kernel: in bf16 NHWC, weights packed by pack_conv_weights_bf16_host
 hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream);
 // kernel HWIO fp32 -> bf16 packed [slab][cc(64 ch)][tap][g(8 groups of 8 ch)][o(128)][8]; dst holds 9*cin*cout uint16

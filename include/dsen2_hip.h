@@ -39,9 +39,9 @@ const char *dsen2_last_error(void);
 /* Number of visible HIP devices whose gcnArchName starts with "gfx950"; <0 on error. */
 int dsen2_device_count(void);
 
-/* Tuning knobs (no reference counterpart).  key 0 = structure of the 128->128 body convolution used by
- * models whose weights are loaded AFTER the call (0 = default; other values are experimental variants
- * kept for A/B measurements, all numerically equivalent up to summation order).  key 1 = timing-only
+/* Tuning knobs (no reference counterpart).  key 0 = structure of the fp32 F->F body convolution used by
+ * models CREATED after the call (14 = default: DMA-fed kernel of conv3x3_body32.hip; 11-13 its sub-variants;
+ * 0-10 = the register-staged kernels kept for A/B measurements; all variants give bit-identical results).  key 1 = timing-only
  * ablation mask of the persistent body kernel (diagnostics: outputs are wrong while it is non-zero).
  * key 2 = output-layer kernel, key 3 = start stagger quantum, key 4 = structure of the bf16 256->256 body
  * convolution (4 = default: 16x16x32 MFMA fed by LDS-DMA, conv3x3_body16.hip; 5, 6 = its residual-prefetch
@@ -78,6 +78,14 @@ int dsen2_model_workspace_bytes(const dsen2_model *m, int n, int h, int w, size_
 int dsen2_model_forward(dsen2_model *m, const float *dev_x10, const float *dev_x20, const float *dev_x60,
                         float *dev_out, int n, int h, int w, void *dev_workspace, size_t workspace_bytes,
                         void *stream);
+
+/* Measurement hook (no reference counterpart): `iters` forward passes exactly as dsen2_model_forward enqueues them,
+ * with a HIP event recorded on `stream` before the first and after the last residual-block convolution of each
+ * pass.  *body_ms_per_launch = mean duration of ONE of those 2*num_layers convolution launches inside the running
+ * network (bench.py's roofline figure).  Synchronises the stream. */
+int dsen2_model_forward_timed(dsen2_model *m, const float *x10, const float *x20, const float *x60, float *out,
+                              int n, int h, int w, void *workspace, size_t workspace_bytes, void *stream, int iters,
+                              float *body_ms_per_launch);
 
 /* ---- single-layer entry points (kernel-level parity tests and benchmarks) -------------------
  * One 3x3 'same' convolution (keras Conv2D as used at utils/DSen2Net.py:10,12,29,35) on NHWC

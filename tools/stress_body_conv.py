@@ -12,12 +12,12 @@ from dsen2_amd.DSen2Net import s2model            # noqa: E402
 
 flat = W.random_he_uniform(10, 6, 6, 128, seed=1, bias_scale=0.05)
 models = {}
-TEST_VARIANT = int(os.environ.get('DSEN2_STRESS_VARIANT', '8'))
+TEST_VARIANT = int(os.environ.get('DSEN2_STRESS_VARIANT', '14'))
 for v in (0, TEST_VARIANT):
     _lib.call('dsen2_set_tuning', 0, v)
     models[v] = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128)
     models[v].set_weights_flat(flat)
-_lib.call('dsen2_set_tuning', 0, 8)
+_lib.call('dsen2_set_tuning', 0, 14)
 bad_total = 0
 SHAPES = [(3, 32, 32, 6), (64, 32, 32, 6), (65, 32, 32, 6), (200, 32, 32, 6), (512, 32, 32, 6),
           (5, 128, 128, 3), (2, 192, 192, 2), (7, 21, 37, 3), (40, 50, 17, 3), (1, 16, 16, 3), (300, 16, 16, 3)]
