@@ -2,9 +2,11 @@
 
     python -m dsen2_amd.build [--force]
 """
+import concurrent.futures
 import os
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
@@ -14,8 +16,9 @@ LIB = os.path.join(HERE, 'libdsen2_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators, so the default contraction would fuse the
 # up-sampler's `scale*dst + offset` (skimage rounds twice) and the residual epilogue's `x + 0.1*t` into FMAs.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-gpu-rdc', '-ffp-contract=off',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-ffp-contract=off',
          '-Wall', '-Wno-unused-function']
+JOBS = int(os.environ.get('DSEN2_BUILD_JOBS', '4'))      # translation units compiled side by side
 
 
 def needs_build():
@@ -29,10 +32,21 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB + '.tmp']
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    # one hipcc process per translation unit (objects in a scratch directory, nothing but the .so is left in-tree)
+    with tempfile.TemporaryDirectory(prefix='dsen2_build_') as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, os.path.splitext(src)[0] + '.o')
+            cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj
+        with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, JOBS)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-fno-gpu-rdc'] + objs + ['-o', LIB + '.tmp']
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
     os.replace(LIB + '.tmp', LIB)
     return LIB
 
