@@ -4,23 +4,9 @@
 // slab) items, one step = (tap, 64 input channels), operand fragments double buffered in registers), with
 // three changes that the bf16 rate makes necessary (profiles/r01_ablation.md):
 //
-//   1. STAGING BY LDS-DMA.  Weight chunks (16 KiB per step) and input chunks go global -> LDS with
-//      `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction, LDS address = M0 + 16*lane, out-of-range lanes
-//      write zeros = the convolution's zero padding).  No staging VGPRs, no ds_write, no select.  The DMAs are
-//      issued from inline asm: hipcc neither tracks them in its waitcnt model (with the builtin it turns every
-//      counted lgkmcnt(N) of the fragment pipeline into lgkmcnt(0)) nor knows about the LDS they write, so the
-//      synchronisation is spelled out here:
-//        - vmcnt retires in ISSUE ORDER, all vector-memory operations of a wave together;
-//        - weight chunk c is issued at the START of step c-3 into ring slot c%4 (last read in step c-4, which
-//          ended with a barrier), retired by every wave's `s_waitcnt vmcnt(N)` at the END of step c-2 — N = the
-//          operations that wave issued after it, a compile-time count — followed by that step's barrier, and
-//          first read by the fragment prefetch at the end of step c-1;
-//        - the six rounds of an input chunk are issued at the start of taps 0-5 of the previous chunk's steps
-//          and are older than the weight DMA whose retirement is awaited at the end of tap 6;
-//        - a wait that assumes FEWER younger operations than there are is stricter, never weaker: the epilogue's
-//          loads and stores are not counted, so they drain within the next item's first step;
-//        - hipcc's own waits (for the epilogue's residual loads) assume fewer operations in flight than there
-//          are, which makes them stricter, never weaker.
+//   1. STAGING BY LDS-DMA (conv3x3_dma.h, which also states the synchronisation rules).  Weight chunks (16 KiB per
+//      step) and input chunks go global -> LDS with `buffer_load_dwordx4 ... lds`: no staging VGPRs, no ds_write, no
+//      select; out-of-range lanes write the zero padding.
 //   2. WEIGHTS ARE THE A OPERAND:  D[row = output channel][col = pixel].  A lane owns ONE pixel (col = lane & 15)
 //      and 4 output channels per accumulator (rows 4*(lane>>4) + r); the weight packing permutes the rows
 //      (pack_conv_weights_bf16_host, perm16) so that the two accumulators of a 32-channel pair hold 8
@@ -34,7 +20,7 @@
 // Per wave: 64 channels x 64 pixels = 4 x 4 accumulators, 2 k-steps of 16 MFMAs and 8 ds_read_b128 per step.
 #include <type_traits>
 
-#include "dsen2_internal.h"
+#include "conv3x3_dma.h"
 
 namespace dsen2 {
 
@@ -52,30 +38,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // alone +0.5 %).  The bf16 copy, the next convolution's input, stays on the default policy.
 constexpr int kAuxNt = 2;
 
-constexpr int KC = 32;                      // 32-bit words per pixel and step = 64 bf16 channels
-constexpr int NT = 128;                     // output channels per item
-constexpr int THREADS = 512;
-constexpr int QS = 336;                     // pixel slots per channel-group row (>= 324 halo pixels, = 0 mod 16)
-constexpr int IN_BYTES = 8 * QS * 16;       // one input chunk buffer: [8 groups][336 slots][16 B] = 43,008
-constexpr int IN_BLOCKS = 6;                // DMA rounds per chunk: 64 pixels each (the last one 16: slots 320-335)
-constexpr int WCH = KC * NT;                // words per weight chunk (16 KiB): [8 k-groups][128 rows][4 words]
-constexpr int NWBUF = 4;
+using dma::KC; using dma::NT; using dma::THREADS; using dma::QS; using dma::IN_BYTES; using dma::IN_BLOCKS;
+using dma::WCH; using dma::NWBUF; using dma::LDS_BYTES; using dma::wait_vmcnt;
 constexpr int KSTEPS = 2;                   // k = 32 channels per MFMA
 constexpr int RS = 4;                       // tile rows per wave
 constexpr int PB = 4, MB = 4;               // 16-pixel rows x 16-channel blocks per wave
-constexpr size_t LDS_BYTES = (size_t)2 * IN_BYTES + (size_t)NWBUF * WCH * 4 + 256 * 4;      // + the bias vector
-static_assert(QS >= kHaloPix && QS % 16 == 0 && 64 * (IN_BLOCKS - 1) + 16 == QS, "input chunk geometry");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   const f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 }  // namespace
@@ -86,7 +57,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int CINW, int COUT, int EPI, int ABL, int PRE>
 __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvParams p, const int n_items) {
   constexpr int NCC = CINW / KC;
-  constexpr int NCHUNK = NCC * 9;
   constexpr int NS = COUT / NT;
   static_assert(NCC % 2 == 0, "input double buffer parity");
   constexpr int N_W = (ABL & 4) ? 0 : 2;                   // weight DMAs per wave and step
@@ -96,8 +66,6 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
   float* const w_s = smem + 2 * IN_BYTES / 4;          // [4][8 k-groups][128 rows][4 words]
   float* const bias_s = w_s + NWBUF * WCH;             // [COUT]: the epilogue must not queue a vector-memory load
                                                        // behind its own stores
-  const unsigned lds_in = (unsigned)(size_t)(__attribute__((address_space(3))) float*)in_s;
-  const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) float*)w_s;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -116,59 +84,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
   const int my_items = (n_items - lid + G - 1) / G;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const size_t img_pix = (size_t)p.h * p.w;
-  // ---- input stream: wave q fetches channel group q (8 channels = 16 B) of 64 halo pixels per DMA ----
-  unsigned in_voff[IN_BLOCKS];      // byte offset of (halo pixel 64*b + lane, group q) inside the image; out of range = zero
-  auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
-  auto set_stage_item = [&](int item) {
-    const int tile = item / NS;
-    const int img = tile / tiles_per_img;
-    const int trem = tile - img * tiles_per_img;
-    const int tyi = trem / p.tiles_x;
-    const int ty0 = tyi * kTile, tx0 = (trem - tyi * p.tiles_x) * kTile;
-    in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)img * img_pix * CINW, 0,
-                                                (unsigned)(img_pix * CINW * 4), 0x00020000);
-#pragma unroll
-    for (int b = 0; b < IN_BLOCKS; ++b) {
-      const int hp = 64 * b + lane;
-      const int hy = hp / kHalo, hx = hp - hy * kHalo;
-      const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-      const bool inb = hp < kHaloPix && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
-      in_voff[b] = inb ? (unsigned)(((gy * p.w + gx) * CINW + wave * 4) * 4) : 0x80000000u;
-    }
-  };
-  // round b of input chunk cc into buffer `buf`
-  auto issue_in = [&](int buf, int b, int cc) {
-    const unsigned m0v = lds_in + buf * IN_BYTES + (wave * QS + 64 * b) * 16;
-    const unsigned so = cc * (KC * 4);
-    if (b < IN_BLOCKS - 1) {
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                   ::"s"(m0v), "v"(in_voff[b]), "s"(in_rsrc), "s"(so) : "memory");
-    } else if (lane < 16) {          // slots 320-335 only: the next group's row starts at 336
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                   ::"s"(m0v), "v"(in_voff[b]), "s"(in_rsrc), "s"(so) : "memory");
-    }
-  };
-
-  // ---- weight stream: 16 waves-instructions of 1 KiB per chunk, two per wave ----
-  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (unsigned)(NS * NCHUNK * WCH * 4), 0x00020000);
-  const unsigned w_voff = lane * 16;
-  int wl_item = lid;           // item / chunk the next issued DMA belongs to
-  int wl_chunk = 0;
-  int st_slot = 0;
-  auto issue_w = [&]() {
-    const unsigned so = (unsigned)(((wl_item % NS) * NCHUNK + wl_chunk) * (WCH * 4) + wave * 1024);
-    const unsigned l0 = lds_w + st_slot * (WCH * 4) + wave * 1024;
-    asm volatile(
-        "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %5 offen lds"
-        ::"s"(l0), "s"(l0 + 8192u), "v"(w_voff), "s"(w_rsrc), "s"(so), "s"(so + 8192u)
-        : "memory");
-    if (++wl_chunk == NCHUNK) {
-      wl_chunk = 0;
-      wl_item = wl_item + G < n_items ? wl_item + G : lid;
-    }
-    st_slot = st_slot == NWBUF - 1 ? 0 : st_slot + 1;
-  };
+  // ---- the two DMA streams (conv3x3_dma.h) ----
+  dma::Stage<CINW, NS> st;
+  st.init(p, in_s, w_s, lane, wave, lid, G, n_items);
 
   // ---- per-lane operand addresses (words) ----
   // B operand (pixels): lane -> pixel column l15 of a 16-pixel row, channel group 4*s + q4 of the chunk
@@ -177,15 +95,15 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
   const int w_lane = (q4 * NT + wn * 64 + l15) * 4;
 
   // ---- prologue: first item's input chunk 0, weight chunks 0-2 ----
-  set_stage_item(lid);
+  st.set_stage_item(lid);
   if constexpr (!(ABL & 8)) {
 #pragma unroll
-    for (int b = 0; b < IN_BLOCKS; ++b) issue_in(0, b, 0);
+    for (int b = 0; b < IN_BLOCKS; ++b) st.issue_in(0, b, 0);
   }
   if constexpr (!(ABL & 4)) {
-    issue_w();
-    issue_w();
-    issue_w();
+    st.issue_w();
+    st.issue_w();
+    st.issue_w();
   }
   if (tid < COUT) bias_s[tid] = p.bias[tid];
   wait_vmcnt<0>();
@@ -317,7 +235,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
       // (on the very last item: its own chunk 0 again, which nobody reads)
       const bool last_cc = cc == NCC - 1;
       const int in_cc = last_cc ? 0 : cc + 1;
-      if (last_cc && have_next_item) set_stage_item(item + G);
+      if (last_cc && have_next_item) st.set_stage_item(item + G);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const float* const wb = w_s + mf_slot * WCH;
@@ -337,8 +255,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
           }
           if (s == 0) {
             // this step's DMAs: input round first, then the weight chunk three steps ahead
-            if (n_in) issue_in((cc + 1) & 1, tap < IN_BLOCKS ? tap : 0, in_cc);
-            if constexpr (!(ABL & 4)) issue_w();
+            if (n_in) st.issue_in((cc + 1) & 1, tap < IN_BLOCKS ? tap : 0, in_cc);
+            if constexpr (!(ABL & 4)) st.issue_w();
             if constexpr (kPre > 0) {
               // the item's last step: its residual values, younger than the step's DMAs, land under its 32 MFMAs
               // (the wait that ends the step then covers them too, which is when they are needed)

@@ -1,6 +1,6 @@
 // conv3x3_body32.hip — fp32 F->F 3x3 'same' convolution (F = 128 or 256): v_mfma_f32_32x32x2_f32 fed by LDS-DMA.
 //
-// The fp32 sibling of conv3x3_body16.hip (read its header for the synchronisation rules of the DMA streams; the
+// The fp32 sibling of conv3x3_body16.hip (the DMA streams and their synchronisation rules: conv3x3_dma.h; the
 // byte geometry is identical: a step is (tap, 32 channels) = 128 B per pixel and a 16 KiB weight chunk):
 //
 //   * weight chunks and input chunks go global -> LDS by `buffer_load_dwordx4 ... lds` issued from inline asm and
@@ -20,7 +20,7 @@
 // 4 ds_read_b128.  Same arithmetic order per output element as conv3x3_body.hip: results are bit-identical.
 #include <type_traits>
 
-#include "dsen2_internal.h"
+#include "conv3x3_dma.h"
 
 namespace dsen2 {
 
@@ -30,26 +30,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KC = 32;                      // input channels (32-bit words) per pixel and step
-constexpr int NT = 128;                     // output channels per item
-constexpr int THREADS = 512;
-constexpr int QS = 336;                     // pixel slots per channel-group row (>= 324 halo pixels, = 0 mod 16)
-constexpr int IN_BYTES = 8 * QS * 16;       // one input chunk buffer: [8 groups of 4 channels][336 slots][16 B]
-constexpr int IN_BLOCKS = 6;                // DMA rounds per chunk: 64 pixels each (the last one 16: slots 320-335)
-constexpr int WCH = KC * NT;                // words per weight chunk (16 KiB): [8 k-groups][128 rows][4 words]
-constexpr int NWBUF = 4;
+using dma::KC; using dma::NT; using dma::THREADS; using dma::QS; using dma::IN_BYTES; using dma::IN_BLOCKS;
+using dma::WCH; using dma::NWBUF; using dma::LDS_BYTES; using dma::wait_vmcnt;
 constexpr int KSTEPS = 4;                   // 8 channels per k-step: one ds_read_b128 feeds 4 MFMAs (k = 2 each)
 constexpr int PB = 2, MB = 2;               // 32-pixel blocks x 32-channel blocks per wave
-constexpr size_t LDS_BYTES = (size_t)2 * IN_BYTES + (size_t)NWBUF * WCH * 4 + 256 * 4;      // + the bias vector
-static_assert(QS >= kHaloPix && QS % 16 == 0 && 64 * (IN_BLOCKS - 1) + 16 == QS, "input chunk geometry");
 static_assert((8 * kHalo) % 16 == 0, "rows R and R+8 of a pixel block sit on the same banks");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 }  // namespace
 
@@ -62,7 +47,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int CIN, int COUT, int EPI, int ABL, int PRE, bool STG, bool DEFER>
 __global__ __launch_bounds__(THREADS, 2) void conv3x3_body32_kernel(const ConvParams p, const int n_items) {
   constexpr int NCC = CIN / KC;
-  constexpr int NCHUNK = NCC * 9;
   constexpr int NS = COUT / NT;
   static_assert(NCC % 2 == 0, "input double buffer parity");
   constexpr int N_W = (ABL & 4) ? 0 : 2;                   // weight DMAs per wave and step
@@ -71,8 +55,6 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body32_kernel(const ConvPa
   float* const in_s = smem;                            // [2][8][QS][4 words]
   float* const w_s = smem + 2 * IN_BYTES / 4;          // [4][8 k-groups][128 rows][4 words]
   float* const bias_s = w_s + NWBUF * WCH;             // [COUT]
-  const unsigned lds_in = (unsigned)(size_t)(__attribute__((address_space(3))) float*)in_s;
-  const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) float*)w_s;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -93,58 +75,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body32_kernel(const ConvPa
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const size_t img_pix = (size_t)p.h * p.w;
 
-  // ---- input stream: wave q fetches channel group q (4 channels = 16 B) of 64 halo pixels per DMA ----
-  unsigned in_voff[IN_BLOCKS];      // byte offset of (halo pixel 64*b + lane, group q) inside the image; out of range = zero
-  auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
-  auto set_stage_item = [&](int item) {
-    const int tile = item / NS;
-    const int img = tile / tiles_per_img;
-    const int trem = tile - img * tiles_per_img;
-    const int tyi = trem / p.tiles_x;
-    const int ty0 = tyi * kTile, tx0 = (trem - tyi * p.tiles_x) * kTile;
-    in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) + (size_t)img * img_pix * CIN, 0,
-                                                (unsigned)(img_pix * CIN * 4), 0x00020000);
-#pragma unroll
-    for (int b = 0; b < IN_BLOCKS; ++b) {
-      const int hp = 64 * b + lane;
-      const int hy = hp / kHalo, hx = hp - hy * kHalo;
-      const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-      const bool inb = hp < kHaloPix && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
-      in_voff[b] = inb ? (unsigned)(((gy * p.w + gx) * CIN + wave * 4) * 4) : 0x80000000u;
-    }
-  };
-  auto issue_in = [&](int buf, int b, int cc) {        // round b of input chunk cc into buffer `buf`
-    const unsigned m0v = lds_in + buf * IN_BYTES + (wave * QS + 64 * b) * 16;
-    const unsigned so = cc * (KC * 4);
-    if (b < IN_BLOCKS - 1) {
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                   ::"s"(m0v), "v"(in_voff[b]), "s"(in_rsrc), "s"(so) : "memory");
-    } else if (lane < 16) {          // slots 320-335 only: the next group's row starts at 336
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                   ::"s"(m0v), "v"(in_voff[b]), "s"(in_rsrc), "s"(so) : "memory");
-    }
-  };
-
-  // ---- weight stream: 16 wave-instructions of 1 KiB per chunk, two per wave ----
-  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (unsigned)(NS * NCHUNK * WCH * 4), 0x00020000);
-  const unsigned w_voff = lane * 16;
-  int wl_item = lid;           // item / chunk the next issued DMA belongs to
-  int wl_chunk = 0;
-  int st_slot = 0;
-  auto issue_w = [&]() {
-    const unsigned so = (unsigned)(((wl_item % NS) * NCHUNK + wl_chunk) * (WCH * 4) + wave * 1024);
-    const unsigned l0 = lds_w + st_slot * (WCH * 4) + wave * 1024;
-    asm volatile(
-        "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %5 offen lds"
-        ::"s"(l0), "s"(l0 + 8192u), "v"(w_voff), "s"(w_rsrc), "s"(so), "s"(so + 8192u)
-        : "memory");
-    if (++wl_chunk == NCHUNK) {
-      wl_chunk = 0;
-      wl_item = wl_item + G < n_items ? wl_item + G : lid;
-    }
-    st_slot = st_slot == NWBUF - 1 ? 0 : st_slot + 1;
-  };
+  // ---- the two DMA streams (conv3x3_dma.h) ----
+  dma::Stage<CIN, NS> st;
+  st.init(p, in_s, w_s, lane, wave, lid, G, n_items);
 
   // ---- per-lane operand addresses (words) ----
   // B operand (pixels): lane -> pixel (row 2*wp + pb + 8*rh, column c16), channel group 2*s + hsel of the chunk
@@ -153,15 +86,15 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body32_kernel(const ConvPa
   const int w_lane = (hsel * NT + wn * 64 + l31) * 4;
 
   // ---- prologue: first item's input chunk 0, weight chunks 0-2 ----
-  set_stage_item(lid);
+  st.set_stage_item(lid);
   if constexpr (!(ABL & 8)) {
 #pragma unroll
-    for (int b = 0; b < IN_BLOCKS; ++b) issue_in(0, b, 0);
+    for (int b = 0; b < IN_BLOCKS; ++b) st.issue_in(0, b, 0);
   }
   if constexpr (!(ABL & 4)) {
-    issue_w();
-    issue_w();
-    issue_w();
+    st.issue_w();
+    st.issue_w();
+    st.issue_w();
   }
   if (tid < COUT) bias_s[tid] = p.bias[tid];
   wait_vmcnt<0>();
@@ -301,7 +234,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body32_kernel(const ConvPa
       // (on the very last item: its own chunk 0 again, which nobody reads)
       const bool last_cc = cc == NCC - 1;
       const int in_cc = last_cc ? 0 : cc + 1;
-      if (last_cc && have_next_item) set_stage_item(item + G);
+      if (last_cc && have_next_item) st.set_stage_item(item + G);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const float* const wb = w_s + mf_slot * WCH;
@@ -332,8 +265,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body32_kernel(const ConvPa
           }
           if (s == MIDS) {
             // this step's DMAs: input round first, then the weight chunk three steps ahead
-            if (n_in) issue_in((cc + 1) & 1, tap < IN_BLOCKS ? tap : 0, in_cc);
-            if constexpr (!(ABL & 4)) issue_w();
+            if (n_in) st.issue_in((cc + 1) & 1, tap < IN_BLOCKS ? tap : 0, in_cc);
+            if constexpr (!(ABL & 4)) st.issue_w();
           }
           if constexpr (DEFER) {
             if (kFirst && tap < 8 && (s == 1 || s == 3)) {
