@@ -53,8 +53,11 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 
 // CINW = words per input pixel (= F / 2).  ABL: timing-only ablation mask as in conv3x3_body.hip
 // (1 no stores, 2 no residual loads, 4 no weight stream, 8 no input stream, 16 no barriers).
-// PRE: accumulator pairs (0-2) whose residual values are fetched under the item's last step (2 spills registers).
-template <int CINW, int COUT, int EPI, int ABL, int PRE>
+// PRE: accumulator pairs (0-2) whose residual values are fetched under the item's last step.
+// ROLLW: register diet for PRE = 2: no second register set for the weight fragments (fragment mb of the next k-step
+// is read into the registers of the current one right after its four MFMAs have issued, 12 MFMAs before its first
+// use) and the input offsets recomputed per round (conv3x3_dma.h, LAZY_VOFF).
+template <int CINW, int COUT, int EPI, int ABL, int PRE, bool ROLLW>
 __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvParams p, const int n_items) {
   constexpr int NCC = CINW / KC;
   constexpr int NS = COUT / NT;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const size_t img_pix = (size_t)p.h * p.w;
   // ---- the two DMA streams (conv3x3_dma.h) ----
-  dma::Stage<CINW, NS> st;
+  dma::Stage<CINW, NS, ROLLW> st;
   st.init(p, in_s, w_s, lane, wave, lid, G, n_items);
 
   // ---- per-lane operand addresses (words) ----
@@ -121,6 +124,15 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
     for (int pb = 0; pb < PB; ++pb) xf[pb] = *reinterpret_cast<const f32x4*>(xp_ + pb * kHalo * 4);
   };
   read_frags(w_cur, x_cur, in_s, w_s, 0, 0);
+  auto read_x = [&](f32x4 (&xf)[PB], const float* ib, int tap, int s) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const float* xp_ = ib + x_lane + (4 * s * QS + dy * kHalo + dx) * 4;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) xf[pb] = *reinterpret_cast<const f32x4*>(xp_ + pb * kHalo * 4);
+  };
+  auto read_w1 = [&](int mb, const float* wb, int s) -> f32x4 {
+    return *reinterpret_cast<const f32x4*>(wb + w_lane + (4 * s * NT) * 4 + mb * 16 * 4);
+  };
 
   // The item loop is ROTATED: an iteration first writes out the PREVIOUS item's accumulators, then runs this item's
   // 36 steps (one extra iteration writes the last item; the first one stores to out-of-range offsets, which the
@@ -246,13 +258,15 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
 
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-          if (s < KSTEPS - 1) {
-            read_frags(w_nxt, x_nxt, ib, wb, tap, s + 1);
-          } else if (tap < 8) {
-            read_frags(w_nxt, x_nxt, ib, wb_nx, tap + 1, 0);
-          } else {
-            read_frags(w_nxt, x_nxt, ib_next, wb_nx, 0, 0);
-          }
+          // fragments of the next k-step: same chunk, or k-step 0 of the next (tap, chunk)
+          const float* const ib_n = s < KSTEPS - 1 || tap < 8 ? ib : ib_next;
+          const float* const wb_n = s < KSTEPS - 1 ? wb : wb_nx;
+          const int tap_n = s < KSTEPS - 1 ? tap : tap < 8 ? tap + 1 : 0;
+          const int s_n = s < KSTEPS - 1 ? s + 1 : 0;
+          if constexpr (ROLLW)
+            read_x(x_nxt, ib_n, tap_n, s_n);
+          else
+            read_frags(w_nxt, x_nxt, ib_n, wb_n, tap_n, s_n);
           if (s == 0) {
             // this step's DMAs: input round first, then the weight chunk three steps ahead
             if (n_in) st.issue_in((cc + 1) & 1, tap < IN_BLOCKS ? tap : 0, in_cc);
@@ -276,14 +290,22 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
+          for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb)
               acc[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w_cur[mb]),
                                                                     __builtin_bit_cast(bf16x8, x_cur[pb]),
                                                                     acc[mb][pb], 0, 0, 0);
+            if constexpr (ROLLW) {
+              __builtin_amdgcn_sched_barrier(0);
+              w_cur[mb] = read_w1(mb, wb_n, s_n);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if constexpr (!ROLLW) {
 #pragma unroll
-          for (int q = 0; q < MB; ++q) w_cur[q] = w_nxt[q];
+            for (int q = 0; q < MB; ++q) w_cur[q] = w_nxt[q];
+          }
 #pragma unroll
           for (int q = 0; q < PB; ++q) x_cur[q] = x_nxt[q];
         }
@@ -304,9 +326,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16_kernel(const ConvPa
   wait_vmcnt<0>();       // no DMA may still be writing this workgroup's LDS when it is released
 }
 
-template <int CINW, int COUT, int EPI, int ABL = 0, int PRE = 0>
+template <int CINW, int COUT, int EPI, int ABL = 0, int PRE = 0, bool ROLLW = false>
 static hipError_t launch_body16_one(const ConvParams& p, hipStream_t stream) {
-  auto kern = conv3x3_body16_kernel<CINW, COUT, EPI, ABL, PRE>;
+  auto kern = conv3x3_body16_kernel<CINW, COUT, EPI, ABL, PRE, ROLLW>;
   static bool attr_set[64] = {};
   static int cus[64] = {};
   int dev = 0;
@@ -342,10 +364,12 @@ hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, in
     return hipErrorInvalidValue;
   }
   if (epilogue == kEpiRelu) return launch_body16_one<128, 256, kEpiRelu>(p, stream);
-  // sub: 0 = first accumulator pair's residual values prefetched (default), 1 = none, 2 = both pairs (12 spills)
-  if (sub == 1) return launch_body16_one<128, 256, kEpiResidual, 0, 0>(p, stream);
-  if (sub == 2) return launch_body16_one<128, 256, kEpiResidual, 0, 2>(p, stream);
-  return launch_body16_one<128, 256, kEpiResidual, 0, 1>(p, stream);
+  // sub: 0 = the whole residual tile prefetched under the last step, with the register diet that makes it fit
+  //      (default: VDSen2 bf16 bench 14.42-14.54 k vs 14.22-14.24 k patches/s for 1, 14.03-14.08 k for 2);
+  //      1 = first accumulator pair prefetched; 2 = no prefetch
+  if (sub == 1) return launch_body16_one<128, 256, kEpiResidual, 0, 1>(p, stream);
+  if (sub == 2) return launch_body16_one<128, 256, kEpiResidual, 0, 0>(p, stream);
+  return launch_body16_one<128, 256, kEpiResidual, 0, 2, true>(p, stream);
 }
 
 }  // namespace dsen2

@@ -50,7 +50,9 @@ __device__ __forceinline__ unsigned lds_address(const float* p) {
 }
 
 // Per-thread state of the two streams.  CINW = 32-bit words per input pixel; NS = output slabs per tile.
-template <int CINW, int NS>
+// LAZY_VOFF: do not keep the six per-lane input offsets in registers across the item but recompute the one a round
+// needs from the staged tile's origin (a dozen VALU operations per step; for kernels that are out of VGPRs).
+template <int CINW, int NS, bool LAZY_VOFF = false>
 struct Stage {
   static constexpr int NCC = CINW / KC;
   static constexpr int NCHUNK = NCC * 9;
@@ -60,7 +62,8 @@ struct Stage {
   size_t img_pix;
   int lane, wave, lid, G, n_items;
   unsigned lds_in, lds_w;
-  unsigned in_voff[IN_BLOCKS];      // byte offset of (halo pixel 64*b + lane, group `wave`) inside the image; out of range = zero
+  unsigned in_voff[LAZY_VOFF ? 1 : IN_BLOCKS];   // byte offset of (halo pixel 64*b + lane, group `wave`) inside the image; out of range = zero
+  int st_y0, st_x0;                 // origin of the staged tile (LAZY_VOFF)
   __amdgpu_buffer_rsrc_t in_rsrc, w_rsrc;
   unsigned w_voff;
   int wl_item, wl_chunk, st_slot;   // item / chunk of the next weight DMA, ring slot it goes to
@@ -76,6 +79,15 @@ struct Stage {
     w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (unsigned)(NS * NCHUNK * WCH * 4), 0x00020000);
     w_voff = lane * 16;
     wl_item = lid; wl_chunk = 0; st_slot = 0;
+    st_y0 = st_x0 = 0;
+  }
+
+  __device__ __forceinline__ unsigned voff_of(int b, int ty0, int tx0) const {
+    const int hp = 64 * b + lane;
+    const int hy = hp / kHalo, hx = hp - hy * kHalo;
+    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const bool inb = hp < kHaloPix && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w;
+    return inb ? (unsigned)(((gy * w + gx) * CINW + wave * 4) * 4) : 0x80000000u;
   }
 
   // the tile whose input the following issue_in() calls fetch
@@ -87,13 +99,12 @@ struct Stage {
     const int ty0 = tyi * kTile, tx0 = (trem - tyi * tiles_x) * kTile;
     in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (size_t)img * img_pix * CINW, 0,
                                                 (unsigned)(img_pix * CINW * 4), 0x00020000);
+    if constexpr (LAZY_VOFF) {
+      st_y0 = ty0;
+      st_x0 = tx0;
+    } else {
 #pragma unroll
-    for (int b = 0; b < IN_BLOCKS; ++b) {
-      const int hp = 64 * b + lane;
-      const int hy = hp / kHalo, hx = hp - hy * kHalo;
-      const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-      const bool inb = hp < kHaloPix && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w;
-      in_voff[b] = inb ? (unsigned)(((gy * w + gx) * CINW + wave * 4) * 4) : 0x80000000u;
+      for (int b = 0; b < IN_BLOCKS; ++b) in_voff[b] = voff_of(b, ty0, tx0);
     }
   }
 
@@ -101,12 +112,13 @@ struct Stage {
   __device__ __forceinline__ void issue_in(int buf, int b, int cc) {
     const unsigned m0v = lds_in + buf * IN_BYTES + (wave * QS + 64 * b) * 16;
     const unsigned so = cc * (KC * 4);
+    const unsigned voff = LAZY_VOFF ? voff_of(b, st_y0, st_x0) : in_voff[LAZY_VOFF ? 0 : b];
     if (b < IN_BLOCKS - 1) {
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                   ::"s"(m0v), "v"(in_voff[b]), "s"(in_rsrc), "s"(so) : "memory");
+                   ::"s"(m0v), "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
     } else if (lane < 16) {          // slots 320-335 only: the next group's row starts at 336
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                   ::"s"(m0v), "v"(in_voff[b]), "s"(in_rsrc), "s"(so) : "memory");
+                   ::"s"(m0v), "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
     }
   }
 
