@@ -528,7 +528,7 @@ hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int 
 // bf16 operands, fp32 accumulate: F -> F with F = 128 or 256 (CIN template argument = F/2 words per pixel)
 hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream) {
   if (epilogue == kEpiResidual && !p.out2) return hipErrorInvalidValue;
-  if (variant >= 4 && variant <= 6)      // 16x16x32 MFMA form fed by LDS-DMA (4, 5, 6 = its sub-variants 0, 1, 2)
+  if (variant >= 4 && variant <= 7)      // 16x16x32 MFMA form fed by LDS-DMA (4-7 = its sub-variants 0-3)
     return launch_conv3x3_body16(p, feat, epilogue, variant - 4, stream);
   // default (2): conv-B on the deferred-epilogue kernel, conv-A on the wave-group-staggered persistent kernel
   if (variant == 2 && feat == 256 && g_body_ablate == 0 && epilogue == kEpiResidual && bodyd_supports(p, 256))

@@ -363,7 +363,8 @@ hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, in
 #undef DSEN2_ABL
     return hipErrorInvalidValue;
   }
-  if (epilogue == kEpiRelu) return launch_body16_one<128, 256, kEpiRelu>(p, stream);
+  if (epilogue == kEpiRelu)      // default: weight fragments reloaded in place (+0.1-0.7 % in the network); sub 3 = double buffered
+    return sub == 3 ? launch_body16_one<128, 256, kEpiRelu>(p, stream) : launch_body16_one<128, 256, kEpiRelu, 0, 0, true>(p, stream);
   // sub: 0 = the whole residual tile prefetched under the last step, with the register diet that makes it fit
   //      (default: VDSen2 bf16 bench 14.42-14.54 k vs 14.22-14.24 k patches/s for 1, 14.03-14.08 k for 2);
   //      1 = first accumulator pair prefetched; 2 = no prefetch

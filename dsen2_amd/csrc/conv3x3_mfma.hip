@@ -320,8 +320,8 @@ static inline uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
-// tuning key 4 (256->256 bf16 body convolution): 4 = 16x16x32 MFMA fed by LDS-DMA (conv3x3_body16.hip; 5, 6 = its
-// residual-prefetch sub-variants); the 32x32x16 forms stay for A/B: 0 = one 8-wave workgroup per CU, 64-channel steps;
+// tuning key 4 (256->256 bf16 body convolution): 4 = 16x16x32 MFMA fed by LDS-DMA (conv3x3_body16.hip; 5-7 = its
+// A/B sub-variants); the 32x32x16 forms stay for A/B: 0 = one 8-wave workgroup per CU, 64-channel steps;
 // 1 = two 4-wave workgroups, 32-channel steps; 2 = conv-A with wave-group stagger + conv-B deferred; 3 = deferred both
 int g_bf16_variant = 4;
 

@@ -62,7 +62,7 @@ hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue,
 void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, int chunk_ch, bool perm16, uint16_t* dst);
 extern int g_bf16_variant;   // tuning key 4 (read when weights are packed and when the kernel is launched)
 inline int bf16_chunk_channels(int variant) { return variant == 1 ? 32 : 64; }   // variants 0, 2, 3 share the packing
-inline bool bf16_perm16(int variant) { return variant >= 4 && variant <= 6; }
+inline bool bf16_perm16(int variant) { return variant >= 4 && variant <= 7; }
 // 16x16x32-MFMA form fed by LDS-DMA (conv3x3_body16.hip), F = 256; weights packed with perm16
 hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, int sub, hipStream_t stream);
 hipError_t launch_f32_to_bf16(const float* in, void* out_bf16, size_t count, hipStream_t stream);

@@ -44,7 +44,7 @@ int dsen2_device_count(void);
  * 0-10 = the register-staged kernels kept for A/B measurements; all variants give bit-identical results).  key 1 = timing-only
  * ablation mask of the persistent body kernel (diagnostics: outputs are wrong while it is non-zero).
  * key 2 = output-layer kernel, key 3 = start stagger quantum, key 4 = structure of the bf16 256->256 body
- * convolution (4 = default: 16x16x32 MFMA fed by LDS-DMA, conv3x3_body16.hip; 5, 6 = its residual-prefetch
+ * convolution (4 = default: 16x16x32 MFMA fed by LDS-DMA, conv3x3_body16.hip; 5-7 = its A/B
  * sub-variants; 0-3 = the 32x32x16 forms of conv3x3_body.hip / conv3x3_bodyd.hip), read when a model is CREATED.  Python: DSEN2_TUNING="key=value,..." applies them at load. */
 int dsen2_set_tuning(int key, int value);
 
