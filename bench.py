@@ -34,6 +34,9 @@ CONFIGS = {
     'vdsen2_20_fp32': dict(metric='32x32x6 patches/sec (VDSen2_20, d=32, F=256, batch 256, fp32)', bands=(4, 6), d=32,
                            f=256, batch=256, precision='fp32', dtype='f32', peak=157.3,
                            workload='VDSen2_20 d=32 F=256 fp32'),
+    'dsen2_20_bf16': dict(metric='32x32x6 patches/sec (DSen2_20, d=6, F=128, batch 512, bf16)', bands=(4, 6), d=6, f=128,
+                          batch=512, precision='bf16', dtype='bf16', peak=2500.0,
+                          workload='DSen2_20 d=6 F=128, bf16 operands / fp32 accumulate + residual stream (not a BASELINE config)'),
     'vdsen2_20_bf16': dict(metric='32x32x6 patches/sec (VDSen2_20, d=32, F=256, batch 256, bf16)', bands=(4, 6), d=32,
                            f=256, batch=256, precision='bf16', dtype='bf16', peak=2500.0,
                            workload='VDSen2_20 d=32 F=256, bf16 operands / fp32 accumulate + residual stream'),
@@ -194,9 +197,8 @@ def main():
                               'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
                               'traffic_source': traffic_src,
                               'kernel': '%s (3x3x%dx%d, %s, persistent)' % (
-                                  'conv3x3_body16_kernel' if bf and FEAT == 256 else 'conv3x3_body_kernel' if bf else 'conv3x3_body32_kernel',
-                                  FEAT, FEAT, ('bf16 MFMA 16x16x32, LDS-DMA staging' if FEAT == 256 else 'bf16 MFMA 32x32x16')
-                                  if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging'),
+                                  'conv3x3_body16_kernel' if bf else 'conv3x3_body32_kernel',
+                                  FEAT, FEAT, 'bf16 MFMA 16x16x32, LDS-DMA staging' if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging'),
                               'ms_per_launch': round(ms, 4), 'ms_per_launch_source': 'HIP events around the %d body-conv launches of %d forward passes' % (2 * NUM_LAYERS, args.steps),
                               'ms_relu_randn': round(ms_relu, 4), 'ms_residual_randn': round(ms_res, 4),
                               'flop_per_launch': flops}

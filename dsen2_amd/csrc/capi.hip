@@ -145,7 +145,8 @@ int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_lay
     L.flat_off = flat;
     flat += (size_t)9 * L.cin * L.cout + L.cout;
     L.bf16 = precision == 1 && L.cin == feature_size && L.cout == feature_size;   // residual-block convolutions only
-    L.bf16_variant = (L.bf16 && feature_size == 256) ? g_bf16_variant : 0;
+    // F = 128 in bf16 has one DMA-fed structure (variant 4) and the register-staged one (0)
+    L.bf16_variant = !L.bf16 ? 0 : feature_size == 256 ? g_bf16_variant : bf16_perm16(g_bf16_variant) ? 4 : 0;
     L.w_off = dev; dev += align_up(L.bf16 ? (size_t)9 * L.cin * L.cout / 2 : packed_weight_floats(L.geom));
     L.b_off = dev; dev += align_up((size_t)L.geom.cout_pad);
     m->layers.push_back(L);
@@ -339,7 +340,7 @@ int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, c
   hipStream_t stream = (hipStream_t)stream_;
   const size_t wn = (size_t)9 * feat * feat;
   std::vector<uint16_t> wb(wn);
-  const int variant = feat == 256 ? g_bf16_variant : 0;
+  const int variant = feat == 256 ? g_bf16_variant : bf16_perm16(g_bf16_variant) ? 4 : 0;
   pack_conv_weights_bf16_host(host_kernel, feat, feat, bf16_chunk_channels(variant), bf16_perm16(variant), wb.data());
   char* dev = nullptr;
   HIP_TRY(hipMalloc((void**)&dev, wn * 2 + feat * sizeof(float)));

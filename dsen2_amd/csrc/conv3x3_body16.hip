@@ -353,6 +353,9 @@ static hipError_t launch_body16_one(const ConvParams& p, hipStream_t stream) {
 
 hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, int sub, hipStream_t stream) {
   if (epilogue == kEpiResidual && !p.out2) return hipErrorInvalidValue;
+  if (feat == 128)       // DSen2 width in bf16 (not a BASELINE config): the default structure only
+    return epilogue == kEpiRelu ? launch_body16_one<64, 128, kEpiRelu, 0, 0, true>(p, stream)
+                                : launch_body16_one<64, 128, kEpiResidual, 0, 2, true>(p, stream);
   if (feat != 256) return hipErrorInvalidValue;
   if (g_body_ablate != 0) {
 #define DSEN2_ABL(M)                                                                     \
