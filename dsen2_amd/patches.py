@@ -95,13 +95,16 @@ def tile_origins(lr_shape, patch_lr, border_lr):
     return org, (ki + 1) * (kj + 1)
 
 
-def gather_patches_device(img_dev, origins_lr, scale, border, patch, n_alloc, divisor=1.0, first=0, count=None):
+def gather_patches_device(img_dev, origins_lr, scale, border, patch, n_alloc, divisor=1.0, first=0, count=None,
+                          origins_dev=None):
     """Crop patches [first, first+count) of one resolution from the (virtually symmetric-padded) image.
 
     img_dev: [H,W,C] float32 CUDA tensor; origins_lr: int32 [used,2] in padded low-res coordinates;
     ``scale`` = resolution ratio to the low-res grid (crop origin and size multiply by it,
     patches.py:67 / :136-137).  Returns [count_or_alloc, C, patch, patch]; rows beyond the used
-    patches are zero as in the reference.
+    patches are zero as in the reference.  ``origins_dev``: the same origins already multiplied by ``scale`` as an
+    int32 [used,2] tensor on the device (``device_origins``) — callers that loop over batches pass it so that no
+    call uploads anything (a pageable host-to-device copy blocks the host until the stream has drained).
     """
     H, W, C = img_dev.shape
     used = origins_lr.shape[0]
@@ -113,12 +116,19 @@ def gather_patches_device(img_dev, origins_lr, scale, border, patch, n_alloc, di
     if n_out > count:
         out[count:].zero_()          # the reference's trailing never-filled patches (patches.py:35)
     if count > 0:
-        org = torch.from_numpy(np.ascontiguousarray(origins_lr[first:first + count] * scale, dtype=np.int32))
-        org = org.to(img_dev.device)
+        if origins_dev is not None:
+            org = origins_dev[first:first + count]
+        else:
+            org = device_origins(origins_lr[first:first + count], scale, img_dev.device)
         with torch.cuda.device(img_dev.device):
             _lib.call('dsen2_tile_gather', _ptr(img_dev), H, W, C, border, _ptr(org), count, patch, float(divisor),
                       _ptr(out), _stream(img_dev.device))
     return out
+
+
+def device_origins(origins_lr, scale, device):
+    """int32 [n,2] crop origins at one resolution (low-res origins x scale) as a device tensor."""
+    return torch.from_numpy(np.ascontiguousarray(origins_lr * scale, dtype=np.int32)).to(device)
 
 
 def get_test_patches(dset_10, dset_20, patchSize=128, border=4, interp=True):
