@@ -278,7 +278,7 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
   if (cin <= 0 || cout <= 0) return false;
   if (epilogue == kEpiSkipNCHW) {
     if (cout > 32 || (cin != 128 && cin != 256)) return false;
-    if (cout <= 16 && g_out_variant == 1) { *g = PackGeom{32, 16, cin, 16, 7}; return true; }   // conv3x3_out.hip
+    if (cout <= 16 && g_out_variant == 1) { *g = PackGeom{16, 16, cin, 16, 7}; return true; }   // conv3x3_out.hip
     *g = PackGeom{32, 32, cin, 32, 0};
     return true;
   }

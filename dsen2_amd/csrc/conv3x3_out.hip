@@ -8,9 +8,9 @@
 // D[px][o] puts output channel o on lane&15 and 4 consecutive pixels in a lane's 4 registers, which is exactly
 // 16 contiguous bytes of an NCHW row: the epilogue is one float4 load (skip) and one float4 store per block.
 //
-// One workgroup = 8 waves = one 16x16 tile; wave w owns tile rows 2w and 2w+1.  LDS: halo tile of 32 channels
-// (double buffered) + the 9 taps x 32 channels x 16 outputs of the current channel chunk (double buffered);
-// one barrier per 32-channel chunk (144 MFMAs per wave).
+// One workgroup = 8 waves = one 16x16 tile; wave w owns tile rows 2w and 2w+1.  LDS: halo tile of 16 channels
+// (double buffered) + the 9 taps x 16 channels x 16 outputs of the current channel chunk (double buffered);
+// one barrier per 16-channel chunk (72 MFMAs per wave); two workgroups per CU.
 #include "dsen2_internal.h"
 
 namespace dsen2 {
@@ -18,17 +18,18 @@ namespace dsen2 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace outk {
-constexpr int KC = 32;
+constexpr int KC = 16;                         // 16-channel chunks: 70 KB of LDS = two workgroups per CU, one's chunk hand-over
+                                               // under the other's MFMAs (32-channel chunks, one workgroup per CU: 205 -> 171 us)
 constexpr int NO = 16;                         // padded output channels
 constexpr int THREADS = 512;
 constexpr int PSTR = KC + 4;
-constexpr int IN_FLOATS = kHaloPix * PSTR;     // 11664
-constexpr int WCH = 9 * KC * NO;               // floats per channel chunk of weights (all 9 taps): 4608
+constexpr int IN_FLOATS = kHaloPix * PSTR;
+constexpr int WCH = 9 * KC * NO;               // floats per channel chunk of weights (all 9 taps)
 constexpr int IN_PIECES = kHaloPix * (KC / 4);
-constexpr int IN_ROUNDS = (IN_PIECES + THREADS - 1) / THREADS;   // 6
-constexpr int W_PIECES = WCH / 4;                                 // 1152
-constexpr int W_ROUNDS = (W_PIECES + THREADS - 1) / THREADS;      // 3
-constexpr size_t LDS_BYTES = (size_t)(2 * IN_FLOATS + 2 * WCH) * sizeof(float);   // 130,176 B
+constexpr int IN_ROUNDS = (IN_PIECES + THREADS - 1) / THREADS;
+constexpr int W_PIECES = WCH / 4;
+constexpr int W_ROUNDS = (W_PIECES + THREADS - 1) / THREADS;
+constexpr size_t LDS_BYTES = (size_t)(2 * IN_FLOATS + 2 * WCH) * sizeof(float);   // 70,272 B
 }  // namespace outk
 
 template <int CIN>

@@ -45,7 +45,7 @@ struct PackGeom { int kc, nt, cin_pad, cout_pad, variant; };
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, hipStream_t stream);
 extern int g_body_variant;
 extern int g_out_variant;
-// last layer, F -> Cout<=16, 16x16x4 MFMA (conv3x3_out.hip); weights packed with KC=32, NT=16
+// last layer, F -> Cout<=16, 16x16x4 MFMA (conv3x3_out.hip); weights packed with KC=16, NT=16
 hipError_t launch_conv3x3_out(const ConvParams& p, int feat, hipStream_t stream);
 extern int g_body_stagger;  // tuning key 3
 extern int g_body_ablate;   // timing-only ablation mask of the persistent body kernel (0 = off)
