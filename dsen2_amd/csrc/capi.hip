@@ -63,12 +63,12 @@ const char* dsen2_last_error(void) { return g_err; }
 
 int dsen2_set_tuning(int key, int value) {
   if (key == 0) {
-    if (value < 0 || value > 14 || value == 7) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
+    if (value != 0 && value != 4 && (value < 8 || value > 14)) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
     g_body_variant = value;
     return DSEN2_OK;
   }
   if (key == 4) {   // bf16 body kernel structure (F = 256): see launch_conv3x3_body_bf16; 4 = 16x16x32 form (conv3x3_body16.hip)
-    if (value < 0 || value > 7) return fail(DSEN2_ERR_INVALID, "bf16 variant %d unknown", value);
+    if (value < 0 || value > 7 || value == 1) return fail(DSEN2_ERR_INVALID, "bf16 variant %d unknown", value);
     g_bf16_variant = value;
     return DSEN2_OK;
   }

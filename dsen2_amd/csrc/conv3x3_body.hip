@@ -501,23 +501,6 @@ hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int 
     return epilogue == kEpiRelu ? launch_body_one<128, 128, kEpiRelu, 32, 8, 0, false, false, true>(p, stream)
                                 : launch_body_one<128, 128, kEpiResidual, 32, 8, 0, false, false, true>(p, stream);
   }
-  if (variant == 6 && feat == 128) {     // A/B: loads issued at the tail of the step
-    return epilogue == kEpiRelu ? launch_body_one<128, 128, kEpiRelu, 32, 8, 0, true>(p, stream)
-                                : launch_body_one<128, 128, kEpiResidual, 32, 8, 0, true>(p, stream);
-  }
-  if (variant == 5 && feat == 128) {
-    return epilogue == kEpiRelu ? launch_body_one<128, 128, kEpiRelu, 16, 4>(p, stream)
-                                : launch_body_one<128, 128, kEpiResidual, 16, 4>(p, stream);
-  }
-  if (g_body_ablate != 0 && feat == 128) {
-#define DSEN2_ABL(M)                                                                              \
-  if (g_body_ablate == M)                                                                         \
-    return epilogue == kEpiRelu ? launch_body_one<128, 128, kEpiRelu, 32, 8, M>(p, stream)        \
-                                : launch_body_one<128, 128, kEpiResidual, 32, 8, M>(p, stream);
-    DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31)
-#undef DSEN2_ABL
-    return hipErrorInvalidValue;
-  }
   if (feat == 128 && epilogue == kEpiRelu) return launch_body_one<128, 128, kEpiRelu>(p, stream);
   if (feat == 128 && epilogue == kEpiResidual) return launch_body_one<128, 128, kEpiResidual>(p, stream);
   if (feat == 256 && epilogue == kEpiRelu) return launch_body_one<256, 256, kEpiRelu>(p, stream);
@@ -537,18 +520,6 @@ hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue,
     return launch_body_one<128, 256, kEpiRelu, 32, 8, 0, false, true, true>(p, stream);
   if (variant == 3 && feat == 256 && bodyd_supports(p, 256))      // A/B: deferred kernel for both epilogues
     return launch_conv3x3_bodyd(p, 256, epilogue, true, stream);
-  if (variant == 1 && feat == 256)    // two 4-wave workgroups per CU, 32-channel steps, wave tile 64 ch x 128 px
-    return epilogue == kEpiRelu ? launch_body_one<128, 256, kEpiRelu, 16, 4, 0, false, true>(p, stream)
-                                : launch_body_one<128, 256, kEpiResidual, 16, 4, 0, false, true>(p, stream);
-  if (g_body_ablate != 0 && feat == 256) {
-#define DSEN2_ABL(M)                                                                                         \
-  if (g_body_ablate == M)                                                                                    \
-    return epilogue == kEpiRelu ? launch_body_one<128, 256, kEpiRelu, 32, 8, M, false, true>(p, stream)      \
-                                : launch_body_one<128, 256, kEpiResidual, 32, 8, M, false, true>(p, stream);
-    DSEN2_ABL(1) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31)
-#undef DSEN2_ABL
-    return hipErrorInvalidValue;
-  }
   if (feat == 256 && epilogue == kEpiRelu) return launch_body_one<128, 256, kEpiRelu, 32, 8, 0, false, true>(p, stream);
   if (feat == 256 && epilogue == kEpiResidual) return launch_body_one<128, 256, kEpiResidual, 32, 8, 0, false, true>(p, stream);
   if (feat == 128 && epilogue == kEpiRelu) return launch_body_one<64, 128, kEpiRelu, 32, 8, 0, false, true>(p, stream);

@@ -271,7 +271,8 @@ int g_out_variant = 1;    // 1 = 16x16x4 output-layer kernel (conv3x3_out.hip); 
 // tuning key 0 (dsen2_set_tuning): structure used for the F->F fp32 body convolutions packed from now on
 //   14 = DMA-fed kernel, deferred epilogue + wave-group stagger (conv3x3_body32.hip; 11-13 = its sub-variants 0-2);
 //   8 = register-staged persistent kernels: conv-A staggered (9), conv-B deferred (conv3x3_bodyd.hip; 10 = deferred both);
-//   4 = persistent kernel (conv3x3_body.hip); 0 = one tile per workgroup; 1-3, 5, 6 = earlier A/B variants
+//   4 = persistent kernel (conv3x3_body.hip); 0 = one tile per workgroup (the first correct version, kept as the
+//   independent implementation tools/stress_body_conv.py compares against)
 int g_body_variant = 14;
 
 bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
@@ -286,7 +287,7 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
   if (cin <= 16) { *g = PackGeom{16, 128, 16, cout, 0}; return true; }
   if (cin == 128 && cout == 128) {
     const int v = g_body_variant;
-    *g = PackGeom{(v == 1 || v == 2 || v == 5) ? 16 : 32, 128, cin, cout, v};   // 8, 9, 10 share variant 4's packing
+    *g = PackGeom{32, 128, cin, cout, v};   // every structure reads the same packing
     return true;
   }
   if (cin == 256 && cout == 256) {   // no deferred form (8 chunks): persistent kernel, or the DMA-fed one (11-14)
@@ -360,21 +361,6 @@ hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogu
     return launch_conv3x3_bodyd(p, 128, epilogue, false, stream);      // A/B: deferred kernel for both epilogues
   if (geom.variant >= 4 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)
     return launch_conv3x3_body(p, cin_pad, epilogue, (geom.variant == 8 || geom.variant == 10) ? 4 : geom.variant, stream);
-  if (cin_pad == 128 && cout_pad == 128 && epilogue != kEpiSkipNCHW && geom.variant != 0) {
-    const bool relu = epilogue == kEpiRelu;
-    switch (geom.variant) {
-      case 1:   // KC=16, 8 waves, 4 waves/SIMD -> 2 workgroups per CU
-        return relu ? launch_one<128, 16, 128, 128, kEpiRelu, 8, 4>(p, stream)
-                    : launch_one<128, 16, 128, 128, kEpiResidual, 8, 4>(p, stream);
-      case 2:   // KC=16, 4 waves (64 ch x 128 px each), 2 workgroups per CU
-        return relu ? launch_one<128, 16, 128, 128, kEpiRelu, 4, 2>(p, stream)
-                    : launch_one<128, 16, 128, 128, kEpiResidual, 4, 2>(p, stream);
-      case 3:   // KC=32, 4 waves, one workgroup per CU, one wave per SIMD
-        return relu ? launch_one<128, 32, 128, 128, kEpiRelu, 4, 1>(p, stream)
-                    : launch_one<128, 32, 128, 128, kEpiResidual, 4, 1>(p, stream);
-      default: return hipErrorInvalidValue;
-    }
-  }
 #define DSEN2_CASE(CI, KC_, CO, NT_, EP) \
   if (cin_pad == CI && cout_pad == CO && epilogue == EP) return launch_one<CI, KC_, CO, NT_, EP>(p, stream);
   DSEN2_CASE(16, 16, 128, 128, kEpiRelu)

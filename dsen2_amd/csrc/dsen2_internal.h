@@ -61,7 +61,7 @@ hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue,
 // perm16: row o of a slab holds output channel 32*(o>>5) + 8*((o&15)>>2) + 4*((o>>4)&1) + (o&3) (conv3x3_body16.hip)
 void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, int chunk_ch, bool perm16, uint16_t* dst);
 extern int g_bf16_variant;   // tuning key 4 (read when weights are packed and when the kernel is launched)
-inline int bf16_chunk_channels(int variant) { return variant == 1 ? 32 : 64; }   // variants 0, 2, 3 share the packing
+inline int bf16_chunk_channels(int) { return 64; }   // every structure stages 64-channel chunks
 inline bool bf16_perm16(int variant) { return variant >= 4 && variant <= 7; }
 // 16x16x32-MFMA form fed by LDS-DMA (conv3x3_body16.hip), F = 256; weights packed with perm16
 hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, int sub, hipStream_t stream);

@@ -7,7 +7,7 @@ from dsen2_amd import _lib, weights as W
 from dsen2_amd.DSen2Net import s2model
 H, F, B = 32, 256, int(os.environ.get('AB_BATCH', 256))
 flat = W.random_he_uniform(10, 6, 2, F, seed=1, bias_scale=0.05)
-VARIANTS = tuple(int(v) for v in sys.argv[1].split(',')) if len(sys.argv) > 1 else (0, 1, 2, 3, 4, 5)
+VARIANTS = tuple(int(v) for v in sys.argv[1].split(',')) if len(sys.argv) > 1 else (2, 3, 4, 5, 6, 7)
 ms = {}
 for v in VARIANTS:
     _lib.call('dsen2_set_tuning', 4, v)

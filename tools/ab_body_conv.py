@@ -16,7 +16,7 @@ from dsen2_amd import _lib, weights as W          # noqa: E402
 from dsen2_amd.DSen2Net import s2model            # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--variants', default='0,4,5')
+ap.add_argument('--variants', default='8,14')
 ap.add_argument('--rounds', type=int, default=5)
 ap.add_argument('--batch', type=int, default=512)
 ap.add_argument('--hw', type=int, default=32)
@@ -31,7 +31,7 @@ for v in variants:
     m = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128)
     m.set_weights_flat(flat)
     models[v] = m
-_lib.call('dsen2_set_tuning', 0, 0)
+_lib.call('dsen2_set_tuning', 0, 14)
 
 B, H = args.batch, args.hw
 a = torch.randn((B, H, H, 128), device='cuda')

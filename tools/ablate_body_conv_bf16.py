@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Timing-only ablations of the bf16 body kernel (F=256, B=256): 1 no stores, 2 no residual loads, 4 no weight
-stream, 8 no input stream, 16 no barriers."""
+stream, 8 no input stream, 16 no barriers.
+The masks act on the DMA-fed kernels (conv3x3_body32.hip / conv3x3_body16.hip: the defaults); the register-staged
+kernels ignore them."""
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
