@@ -116,20 +116,78 @@ class S2Model(object):
         """keras Model.predict: list of NCHW float32 ndarrays -> ndarray [N, cout, H, W].
 
         ``batch_size`` only bounds device memory (results do not depend on it); default: as many
-        patches as fit ``max_workspace_bytes``.
+        patches as fit ``max_workspace_bytes``.  With more than one batch the host<->device copies are pipelined:
+        batch i+1 is staged (page-locked buffer, copy stream) and batch i-1 is downloaded while batch i computes.
         """
         xs = [np.ascontiguousarray(a, dtype=np.float32) for a in x]
+        if len(xs) != len(self.bands):
+            raise ValueError('expected %d inputs, got %d' % (len(self.bands), len(xs)))
         n, _, h, w = xs[0].shape
+        for a, c in zip(xs, self.bands):
+            if a.shape != (n, c, h, w):
+                raise ValueError('input of shape %r where %r is expected' % (a.shape, (n, c, h, w)))
         bs = self.batch_limit(h, w) if batch_size is None else int(batch_size)
         out = np.empty((n, self.cout, h, w), np.float32)
-        for i0 in range(0, n, bs):
-            i1 = min(n, i0 + bs)
-            dev = [torch.from_numpy(a[i0:i1]).to(self.device, non_blocking=False) for a in xs]
-            y = self.forward_device(dev)
-            out[i0:i1] = y.cpu().numpy()
-            if verbose:
-                sys.stdout.write('\r%d/%d' % (i1, n))
-                sys.stdout.flush()
+        starts = list(range(0, n, bs))
+        if len(starts) <= 1:
+            for i0 in starts:
+                dev = [torch.from_numpy(a[i0:n]).to(self.device, non_blocking=False) for a in xs]
+                out[i0:n] = self.forward_device(dev).cpu().numpy()
+                self._progress(verbose, n, n)
+            return self._progress_end(verbose, out)
+
+        with torch.cuda.device(self.device):
+            comp = torch.cuda.current_stream(self.device)
+            h2d, d2h = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+            slots = []
+            for _ in range(2):
+                slots.append(dict(
+                    pin_in=[torch.empty((bs, c, h, w), dtype=torch.float32, pin_memory=True) for c in self.bands],
+                    dev_in=[torch.empty((bs, c, h, w), dtype=torch.float32, device=self.device) for c in self.bands],
+                    dev_out=torch.empty((bs, self.cout, h, w), dtype=torch.float32, device=self.device),
+                    pin_out=torch.empty((bs, self.cout, h, w), dtype=torch.float32, pin_memory=True),
+                    ev_in=torch.cuda.Event(), ev_comp=torch.cuda.Event(), ev_out=torch.cuda.Event(), span=None))
+
+            def collect(slot):                      # batch whose download was issued from this slot
+                if slot['span'] is not None:
+                    slot['ev_out'].synchronize()
+                    j0, j1 = slot['span']
+                    out[j0:j1] = slot['pin_out'][:j1 - j0].numpy()
+                    slot['span'] = None
+                    self._progress(verbose, j1, n)
+
+            for i, i0 in enumerate(starts):
+                i1 = min(n, i0 + bs)
+                m = i1 - i0
+                slot = slots[i & 1]
+                collect(slot)                       # batch i-2: after this the slot's buffers are all free
+                for k, a in enumerate(xs):          # host copy into page-locked memory, under batch i-1's compute
+                    slot['pin_in'][k][:m].numpy()[...] = a[i0:i1]
+                with torch.cuda.stream(h2d):
+                    for k in range(len(xs)):
+                        slot['dev_in'][k][:m].copy_(slot['pin_in'][k][:m], non_blocking=True)
+                    slot['ev_in'].record(h2d)
+                comp.wait_event(slot['ev_in'])
+                self.forward_device([t[:m] for t in slot['dev_in']], out=slot['dev_out'][:m])
+                slot['ev_comp'].record(comp)
+                with torch.cuda.stream(d2h):
+                    d2h.wait_event(slot['ev_comp'])
+                    slot['pin_out'][:m].copy_(slot['dev_out'][:m], non_blocking=True)
+                    slot['ev_out'].record(d2h)
+                slot['span'] = (i0, i1)
+            last = len(starts) - 1
+            collect(slots[(last - 1) & 1])
+            collect(slots[last & 1])
+        return self._progress_end(verbose, out)
+
+    @staticmethod
+    def _progress(verbose, done, total):
+        if verbose:
+            sys.stdout.write('\r%d/%d' % (done, total))
+            sys.stdout.flush()
+
+    @staticmethod
+    def _progress_end(verbose, out):
         if verbose:
             sys.stdout.write('\n')
         return out
