@@ -21,6 +21,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL between processes needs dmabuf IPC on this driver stack; must be in the environment before HIP initialises
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 H = W = 32
 # BASELINE.json configs.  The default (what the driver runs) is configs[1]; the others are for our own runs.

@@ -8,6 +8,8 @@ GPUs of a node (one process per GPU, RCCL all-gather of the predictions: dsen2_a
     (--backend gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks)
 Rank 0 prints one JSON line with wall times.  Random-init weights; the data is synthetic.
 """
+import os
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # RCCL between processes: dmabuf IPC
 import argparse
 import contextlib
 import io
