@@ -20,6 +20,14 @@ def test_body_conv_matches_reference_structure_over_many_runs():
     assert 'total mismatching elements = 0' in p.stdout
 
 
+def test_bf16_body_conv_matches_reference_structure_over_many_runs():
+    """Same screen for the DMA-fed bf16 kernel (F = 256 and 128) against the register-staged structure, bit for bit."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stress_body_conv_bf16.py')], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert 'total mismatching elements = 0' in p.stdout
+
+
 def test_forward_is_bitwise_reproducible_across_launches():
     from dsen2_amd import weights as W
     from dsen2_amd.DSen2Net import s2model

@@ -19,10 +19,11 @@ for v in (0, TEST_VARIANT):
     models[v].set_weights_flat(flat)
 _lib.call('dsen2_set_tuning', 0, 14)
 bad_total = 0
-SHAPES = [(3, 32, 32, 6), (64, 32, 32, 6), (65, 32, 32, 6), (200, 32, 32, 6), (512, 32, 32, 6),
+MULT = int(os.environ.get('DSEN2_STRESS_REPS', '1'))
+SHAPES = [(3, 32, 32, 6), (64, 32, 32, 6), (65, 32, 32, 6), (200, 32, 32, 6), (512, 32, 32, 6), (1, 1, 1, 2), (2, 5, 70, 2),
           (5, 128, 128, 3), (2, 192, 192, 2), (7, 21, 37, 3), (40, 50, 17, 3), (1, 16, 16, 3), (300, 16, 16, 3)]
 for B, HH, WW, REPS in SHAPES:
-    for rep in range(REPS):
+    for rep in range(REPS * MULT):
         a = torch.randn((B, HH, WW, 128), device='cuda'); r = torch.randn((B, HH, WW, 128), device='cuda')
         for layer in (1, 2):
             o0 = torch.empty_like(a); o4 = torch.empty_like(a)
