@@ -13,8 +13,11 @@
 //     accumulator, channels (r & 3) + 8*(r >> 2) + 4*(lane >> 5): register quad g = 16 contiguous bytes of NHWC,
 //     the two half-waves together 32 contiguous bytes per pixel.  The epilogue is 16-byte loads/stores with no
 //     cross-lane transposes (the X-as-A form needs 64 dword stores or 256 DPP moves per lane and item);
-//   * the residual tile (kEpiResidual) is fetched under the item's last step into registers that the DMA staging
-//     freed; the epilogue's stores drain under the next item's first step (3.5 us).
+//   * default (DEFER): the finished accumulators are copied to a second register set — the DMA staging freed the
+//     registers — and written out in 16 pieces inside the next item's first 8 steps, residual quads fetched one
+//     step ahead; without DEFER the residual tile is fetched under the item's last step (PRE) and the epilogue's
+//     stores drain under the next item's first step (3.5 us);
+//   * waves 4-7 issue their DMAs half a step after waves 0-3 (STG).
 //
 // Per wave: 64 channels x 64 pixels = 2 x 2 accumulators of 32x32; one step = 4 k-steps of 16 MFMAs and
 // 4 ds_read_b128.  Same arithmetic order per output element as conv3x3_body.hip: results are bit-identical.
