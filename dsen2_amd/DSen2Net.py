@@ -217,27 +217,62 @@ def s2model(input_shape, num_layers=32, feature_size=256, device=None, precision
     return S2Model(input_shape, num_layers, feature_size, device=device, precision=precision)
 
 
-def conv3x3_body_bf16(x_bf16, kernel_hwio, bias, epilogue=0, aux=None, res_scale=RES_SCALE):
-    """Kernel-level entry point of the bf16 body convolution: x_bf16 NHWC torch.bfloat16 CUDA tensor.
-    Returns bf16 NHWC (epilogue 0) or (fp32 NHWC, bf16 NHWC copy) (epilogue 1)."""
+def to_blocked(x_nhwc):
+    """[n,h,w,c] -> the blocked layout of the bf16 kernels [n, c/8, h, w, 8] (a torch reshuffle, test helper)."""
+    n, h, w, c = x_nhwc.shape
+    return x_nhwc.reshape(n, h, w, c // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
+
+
+def from_blocked(x_blk):
+    n, b, h, w, e = x_blk.shape
+    return x_blk.permute(0, 2, 3, 1, 4).reshape(n, h, w, b * e).contiguous()
+
+
+def split_f32(x):
+    """fp32 NHWC CUDA tensor -> (hi, lo): blocked int16 tensors [n, c/8, h, w, 8] (include/dsen2_hip.h: dsen2_split_f32)."""
+    x = x.contiguous()
+    n, h, w, c = x.shape
+    hi = torch.empty((n, c // 8, h, w, 8), dtype=torch.int16, device=x.device)
+    lo = torch.empty_like(hi)
+    with torch.cuda.device(x.device):
+        _lib.call('dsen2_split_f32', _ptr(x), _ptr(hi), _ptr(lo), n, h, w, c, _stream_ptr(x.device))
+    return hi, lo
+
+
+def join_f32(hi, lo):
+    n, b, h, w, e = hi.shape
+    out = torch.empty((n, h, w, b * e), dtype=torch.float32, device=hi.device)
+    with torch.cuda.device(hi.device):
+        _lib.call('dsen2_join_f32', _ptr(hi), _ptr(lo), _ptr(out), n, h, w, b * e, _stream_ptr(hi.device))
+    return out
+
+
+def conv3x3_body_bf16(x_bf16, kernel_hwio, bias, epilogue=0, res_hi=None, res_lo=None, res_scale=RES_SCALE):
+    """Kernel-level entry point of the bf16 body convolution: x_bf16 NHWC torch.bfloat16 CUDA tensor (reshuffled to
+    the kernel's blocked layout here).  epilogue 0: returns relu(conv + bias) as bf16 NHWC.  epilogue 1: updates the
+    residual stream's blocked planes (res_hi, res_lo; see split_f32) in place and returns them.  epilogue 3:
+    returns the updated residual stream as fp32 NHWC (planes untouched)."""
     n, h, w, feat = x_bf16.shape
     kernel_hwio = np.ascontiguousarray(kernel_hwio, np.float32)
     bias = np.ascontiguousarray(bias, np.float32)
+    xb = to_blocked(x_bf16)
+    out = None
     if epilogue == 0:
-        out = torch.empty((n, h, w, feat), dtype=torch.bfloat16, device=x_bf16.device)
-        out2 = None
-    else:
+        out = torch.empty((n, feat // 8, h, w, 8), dtype=torch.bfloat16, device=x_bf16.device)
+    elif epilogue == 3:
         out = torch.empty((n, h, w, feat), dtype=torch.float32, device=x_bf16.device)
-        out2 = torch.empty((n, h, w, feat), dtype=torch.bfloat16, device=x_bf16.device)
     with torch.cuda.device(x_bf16.device):
-        _lib.call('dsen2_conv3x3_body_bf16', _ptr(x_bf16), kernel_hwio.ctypes.data_as(_lib.c_float_p),
-                  bias.ctypes.data_as(_lib.c_float_p), _ptr(aux), _ptr(out), _ptr(out2), n, h, w, feat, int(epilogue),
+        _lib.call('dsen2_conv3x3_body_bf16', _ptr(xb), kernel_hwio.ctypes.data_as(_lib.c_float_p),
+                  bias.ctypes.data_as(_lib.c_float_p), _ptr(res_hi), _ptr(res_lo), _ptr(out), n, h, w, feat, int(epilogue),
                   float(res_scale), _stream_ptr(x_bf16.device))
-    return out if epilogue == 0 else (out, out2)
+    if epilogue == 1:
+        return res_hi, res_lo
+    return from_blocked(out) if epilogue == 0 else out
 
 
-def conv3x3_nhwc(x, kernel_hwio, bias, epilogue=0, aux=None, res_scale=RES_SCALE):
-    """Single-layer entry point (kernel-level parity tests): x NHWC float32 CUDA tensor."""
+def conv3x3_nhwc(x, kernel_hwio, bias, epilogue=0, aux=None, res_scale=RES_SCALE, ref=False):
+    """Single-layer entry point (kernel-level parity tests): x NHWC float32 CUDA tensor.  ref=True runs the
+    one-tile-per-workgroup kernel (dsen2_conv3x3_nhwc_ref), the independent structure for cross-checks."""
     n, h, w, cin = x.shape
     kernel_hwio = np.ascontiguousarray(kernel_hwio, np.float32)
     bias = np.ascontiguousarray(bias, np.float32)
@@ -247,7 +282,7 @@ def conv3x3_nhwc(x, kernel_hwio, bias, epilogue=0, aux=None, res_scale=RES_SCALE
     else:
         out = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.call('dsen2_conv3x3_nhwc', _ptr(x), kernel_hwio.ctypes.data_as(_lib.c_float_p),
+        _lib.call('dsen2_conv3x3_nhwc_ref' if ref else 'dsen2_conv3x3_nhwc', _ptr(x), kernel_hwio.ctypes.data_as(_lib.c_float_p),
                   bias.ctypes.data_as(_lib.c_float_p), _ptr(aux), _ptr(out), n, h, w, cin, cout, int(epilogue),
                   float(res_scale), _stream_ptr(x.device))
     return out

@@ -23,7 +23,6 @@ SIGNATURES = {
     'dsen2_version': (ctypes.c_char_p, []),
     'dsen2_last_error': (ctypes.c_char_p, []),
     'dsen2_device_count': (c_int, []),
-    'dsen2_set_tuning': (c_int, [c_int, c_int]),
     'dsen2_model_create': (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int]),
     'dsen2_model_destroy': (None, [c_void_p]),
     'dsen2_model_num_params': (c_size_t, [c_void_p]),
@@ -35,6 +34,10 @@ SIGNATURES = {
                                           c_void_p, c_size_t, c_void_p, c_int, c_float_p]),
     'dsen2_conv3x3_nhwc': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_int, c_int, ctypes.c_float, c_void_p]),
+    'dsen2_conv3x3_nhwc_ref': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, ctypes.c_float, c_void_p]),
+    'dsen2_split_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dsen2_join_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dsen2_conv3x3_body_bf16': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                         c_int, c_int, ctypes.c_float, c_void_p]),
     'dsen2_model_time_body_conv': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -73,14 +76,26 @@ def load():
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = lib
-        # DSEN2_TUNING="key=value,key=value": dsen2_set_tuning() calls applied at load time (A/B runs of whole
-        # scripts and test suites against a non-default kernel structure; see include/dsen2_hip.h for the keys)
-        for kv in filter(None, os.environ.get('DSEN2_TUNING', '').split(',')):
+        # Diagnostic builds only (python -m dsen2_amd.build --diag, selected with DSEN2_HIP_LIB): DSEN2_DIAG_SET=
+        # "key=value,..." applies dsen2_diag_set() at load time (tools/: A/B of kernel structures, ablations).  The
+        # product library has no such switch; asking it for one is an error, not a silent no-op.
+        want = list(filter(None, os.environ.get('DSEN2_DIAG_SET', '').split(',')))
+        if want and not hasattr(lib, 'dsen2_diag_set'):
+            raise ImportError('DSEN2_DIAG_SET is set but %s is not a diagnostic build' % LIB_PATH)
+        for kv in want:
             key, value = kv.split('=')
-            code = lib.dsen2_set_tuning(int(key), int(value))
-            if code != OK:
-                raise DSen2Error(code, lib.dsen2_last_error().decode('utf-8', 'replace'))
+            diag_set(int(key), int(value))
     return _lib
+
+
+def diag_set(key, value):
+    """dsen2_diag_set of a -DDSEN2_DIAG library (tools/ only); raises on the product library."""
+    lib = load()
+    if not hasattr(lib, 'dsen2_diag_set'):
+        raise DSen2Error(ERR_INVALID, '%s is not a diagnostic build (python -m dsen2_amd.build --diag)' % LIB_PATH)
+    fn = lib.dsen2_diag_set
+    fn.restype, fn.argtypes = c_int, [c_int, c_int]
+    check(fn(int(key), int(value)))
 
 
 def check(code):

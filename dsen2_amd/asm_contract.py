@@ -1,0 +1,127 @@
+"""Compile-time contract of the inline-asm LDS-DMA kernels (conv3x3_body32.hip, conv3x3_body16w.hip).
+
+The DMAs are issued from inline asm and synchronised by hand-counted `s_waitcnt vmcnt(N)`; both rest on
+properties of the generated code that a toolchain or flag change could silently break.  `check_sources` compiles
+the two translation units to ISA with exactly the product's flags and fails (AsmContractError) unless
+
+  * every mention of M0 belongs to a DMA statement, which saves M0, sets it, waits one state, issues
+    `buffer_load_dwordx4 ... lds` and restores M0 (hipcc reserves M0 and refuses it in a clobber list, so the
+    statements preserve it themselves);
+  * every `buffer_load_dwordx4 ... lds` is one of those statements;
+  * no kernel spills (a scratch access is a vector-memory operation: hipcc waits for a reload with vmcnt(0), which
+    drains the DMA queue, and it is not in the hand counts);
+  * every kernel ends with `s_waitcnt vmcnt(0)` before `s_endpgm` (no DMA may still be writing LDS that already
+    belongs to the next workgroup);
+  * the bf16 kernel's epilogues contain exactly the number of vector-memory operations its first-chunk waits count
+    as younger than their target (conv3x3_body16w.hip, E_OPS): an over-count there would be a weaker wait.
+
+dsen2_amd.build runs it on every product build; tests/test_dma_asm_contract.py runs it in the CPU suite.
+"""
+import os
+import re
+import subprocess
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+DMA_SOURCES = ['conv3x3_body32.hip', 'conv3x3_body16w.hip']
+
+
+class AsmContractError(RuntimeError):
+    pass
+
+
+def _code_lines(text):
+    return [ln.strip() for ln in text.splitlines() if ln.strip() and not ln.strip().startswith((';', '.', '//'))]
+
+
+def _kernels(text):
+    """name -> list of instruction lines, for every kernel in an ISA listing."""
+    out, name, body = {}, None, []
+    for ln in text.splitlines():
+        m = re.match(r'^(_Z\w+):', ln)
+        if m:
+            name, body = m.group(1), []
+            continue
+        if name is not None:
+            t = ln.strip()
+            if t and not t.startswith((';', '.', '//')):
+                body.append(t.split(';')[0].strip())
+            if t.startswith('s_endpgm'):
+                out[name] = body
+                name = None
+    return out
+
+
+def check_listing(text, src):
+    code = _code_lines(text)
+    code = [ln.split(';')[0].strip() for ln in code]
+
+    def need(cond, msg, ctx=()):
+        if not cond:
+            raise AsmContractError('%s: %s %s' % (src, msg, list(ctx)))
+
+    m0 = [i for i, ln in enumerate(code) if re.search(r'\bm0\b', ln)]
+    need(m0, 'no M0 use found (the DMA statements are gone?)')
+    dma = [i for i, ln in enumerate(code) if ln.startswith('buffer_load_dwordx4') and ln.endswith('lds')]
+    need(dma, 'no LDS-DMA instruction found')
+    allowed = set()
+    for i in dma:
+        need(code[i - 1] == 's_nop 0' and re.match(r's_mov_b32 m0, s\d+', code[i - 2]), 'DMA without its M0 write + wait state',
+             code[i - 2:i + 1])
+        allowed.update((i - 2,))
+        # the statement's save (before the first M0 write) and restore (after the last DMA)
+        j = i - 3
+        if re.match(r's_mov_b32 s\d+, m0', code[j]):
+            allowed.add(j)
+        k = i + 1
+        if re.match(r's_mov_b32 m0, s\d+', code[k]):
+            allowed.add(k)
+    for i in m0:
+        need(i in allowed, 'M0 touched outside a DMA statement', code[max(0, i - 2):i + 3])
+    saves = sum(1 for ln in code if re.match(r's_mov_b32 s\d+, m0', ln))
+    need(saves > 0, 'the DMA statements no longer save M0')
+    need(not any('scratch_' in ln for ln in code), 'a DMA kernel spills registers')
+    kernels = _kernels(text)
+    need(kernels, 'no kernel found')
+    n_dma_kernels = 0
+    for name, body in kernels.items():
+        if not any(ln.startswith('buffer_load_dwordx4') and ln.endswith('lds') for ln in body):
+            continue                       # a kernel without LDS-DMA (the split / join helpers)
+        n_dma_kernels += 1
+        back = [ln for ln in body[-40:] if ln.startswith('s_waitcnt') and 'vmcnt' in ln]
+        need(back and back[-1].replace(' ', '') in ('s_waitcntvmcnt(0)', 's_waitcntvmcnt(0)lgkmcnt(0)'),
+             'kernel %s does not drain its DMAs before s_endpgm' % name, back[-3:])
+    need(n_dma_kernels > 0, 'no LDS-DMA kernel found')
+    if src == 'conv3x3_body16w.hip':
+        # E_OPS of the kernel: epilogue 0 = 16 stores; 1 and 3 = 32 loads + 32 stores; (compiler-visible buffer
+        # operations only: the DMAs are `... lds`)
+        expect = {0: (0, 16), 1: (32, 32), 3: (32, 32)}
+        found = 0
+        for name, body in _kernels(text).items():
+            m = re.search(r'conv3x3_body16w_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)
+            if not m or int(m.group(4)) != 0:
+                continue
+            found += 1
+            loads = sum(1 for ln in body if ln.startswith('buffer_load_dwordx4') and not ln.endswith('lds'))
+            stores = sum(1 for ln in body if ln.startswith('buffer_store_dwordx4'))
+            other = [ln for ln in body if re.match(r'(buffer|global|flat)_(load|store|atomic)', ln)
+                     and not ln.startswith(('buffer_load_dwordx4', 'buffer_store_dwordx4'))]
+            # bias preload: global_load_dword in the prologue (before the first vmcnt(0)) is the only other access
+            need(len(other) <= 1, 'unexpected vector-memory instructions in the bf16 body kernel', other[:4])
+            need((loads, stores) == expect[int(m.group(3))],
+                 'epilogue %s has %d loads / %d stores, the waits count %r' % (m.group(3), loads, stores, expect[int(m.group(3))]))
+        need(found >= 6, 'expected the 6 product instantiations of conv3x3_body16w_kernel, found %d' % found)
+
+
+def check_sources(hipcc, flags, verbose=False):
+    with tempfile.TemporaryDirectory(prefix='dsen2_asm_') as tmp:
+        for src in DMA_SOURCES:
+            out = os.path.join(tmp, src + '.s')
+            cmd = [hipcc] + [f for f in flags if f not in ('-fPIC',)] + ['-S', '--cuda-device-only', os.path.join(CSRC, src), '-o', out]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+            with open(out) as f:
+                check_listing(f.read(), src)
+    return True

@@ -34,12 +34,26 @@ int fail(int code, const char* fmt, ...) {
 struct Layer {
   int cin, cout;        // real channel counts (keras)
   int epilogue;
-  bool bf16;            // weights packed as bf16 for the bf16-operand body kernel
-  int bf16_variant;     // structure of that kernel the weights were packed for
+  bool bf16;            // weights packed as bf16 for the bf16-operand body kernel (conv3x3_body16w.hip)
   PackGeom geom;
   size_t w_off, b_off;  // float offsets inside dev_params
   size_t flat_off;      // float offset of the kernel inside the keras-flat array
 };
+
+constexpr int kBf16ChunkChannels = 32;   // input channels per weight chunk of conv3x3_body16w.hip
+
+#ifdef DSEN2_DIAG
+// Diagnostic build only (tools/): defaults copied into models and single-layer calls made AFTER dsen2_diag_set.
+// The product library has no mutable globals — a model's kernel structures are fixed constants.
+Tuning g_diag_tuning;
+#endif
+Tuning default_tuning() {
+#ifdef DSEN2_DIAG
+  return g_diag_tuning;
+#else
+  return Tuning{};
+#endif
+}
 
 constexpr size_t kAlignFloats = 64;   // 256-byte alignment of every device sub-buffer
 size_t align_up(size_t v) { return (v + kAlignFloats - 1) / kAlignFloats * kAlignFloats; }
@@ -49,6 +63,7 @@ size_t align_up(size_t v) { return (v + kAlignFloats - 1) / kAlignFloats * kAlig
 struct dsen2_model {
   int c10, c20, c60, cin, cout, num_layers, feat, precision;
   int device;
+  Tuning tune;          // kernel structures, fixed at creation
   std::vector<Layer> layers;
   size_t n_params;
   size_t dev_param_floats;
@@ -58,36 +73,37 @@ struct dsen2_model {
 
 extern "C" {
 
-const char* dsen2_version(void) { return "dsen2_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+const char* dsen2_version(void) {
+#ifdef DSEN2_DIAG
+  return "dsen2_hip 0.2-diag (gfx950; fp32 MFMA 32x32x2 / bf16 MFMA 16x16x32; DIAGNOSTIC build)";
+#else
+  return "dsen2_hip 0.2 (gfx950; fp32 MFMA 32x32x2 / bf16 MFMA 16x16x32)";
+#endif
+}
 const char* dsen2_last_error(void) { return g_err; }
 
-int dsen2_set_tuning(int key, int value) {
+#ifdef DSEN2_DIAG
+// Diagnostic build only — not declared in include/dsen2_hip.h.  key 0: structure of the fp32 body convolution
+// (14 default, 11-13 sub-variants of conv3x3_body32.hip, 0 one tile per workgroup); key 1: timing-only ablation
+// mask of the persistent body kernels (outputs are WRONG while non-zero); key 2: output-layer kernel (1 / 0).
+int dsen2_diag_set(int key, int value) {
   if (key == 0) {
-    if (value != 0 && value != 4 && (value < 8 || value > 14)) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
-    g_body_variant = value;
+    if (value != 0 && (value < 11 || value > 14)) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
+    g_diag_tuning.body_variant = value;
     return DSEN2_OK;
   }
-  if (key == 4) {   // bf16 body kernel structure (F = 256): see launch_conv3x3_body_bf16; 4 = 16x16x32 form (conv3x3_body16.hip)
-    if (value < 0 || value > 7 || value == 1) return fail(DSEN2_ERR_INVALID, "bf16 variant %d unknown", value);
-    g_bf16_variant = value;
+  if (key == 1) {
+    g_diag_tuning.ablate = value;
     return DSEN2_OK;
   }
-  if (key == 3) {   // start stagger of the persistent body kernel (quantum in units of 8128 cycles; 0 = off)
-    if (value < 0 || value > 64) return fail(DSEN2_ERR_INVALID, "stagger %d out of range", value);
-    g_body_stagger = value;
-    return DSEN2_OK;
-  }
-  if (key == 2) {   // output-layer kernel: 1 = 16x16x4 (default), 0 = padded 32-wide block
+  if (key == 2) {
     if (value != 0 && value != 1) return fail(DSEN2_ERR_INVALID, "output variant %d unknown", value);
-    g_out_variant = value;
+    g_diag_tuning.out_variant = value;
     return DSEN2_OK;
   }
-  if (key == 1) {   // timing-only ablation of the persistent body kernel (wrong results when non-zero)
-    g_body_ablate = value;
-    return DSEN2_OK;
-  }
-  return fail(DSEN2_ERR_INVALID, "unknown tuning key %d", key);
+  return fail(DSEN2_ERR_INVALID, "unknown diagnostic key %d", key);
 }
+#endif
 
 int dsen2_device_count(void) {
   int n = 0;
@@ -121,6 +137,7 @@ int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_lay
   m->c10 = c10; m->c20 = c20; m->c60 = c60; m->cin = cin; m->cout = cout;
   m->num_layers = num_layers; m->feat = feature_size; m->precision = precision;
   m->dev_params = nullptr; m->loaded = false;
+  m->tune = default_tuning();
   if (hipGetDevice(&m->device) != hipSuccess) {
     delete m;
     return fail(DSEN2_ERR_NO_DEVICE, "no HIP device");
@@ -138,15 +155,13 @@ int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_lay
   for (size_t i = 0; i < shapes.size(); ++i) {
     Layer L;
     L.cin = shapes[i].first; L.cout = shapes[i].second; L.epilogue = epis[i];
-    if (!conv_pack_geometry(L.cin, L.cout, L.epilogue, &L.geom)) {
+    if (!conv_pack_geometry(L.cin, L.cout, L.epilogue, m->tune, &L.geom)) {
       delete m;
       return fail(DSEN2_ERR_INVALID, "no kernel for conv %d->%d", L.cin, L.cout);
     }
     L.flat_off = flat;
     flat += (size_t)9 * L.cin * L.cout + L.cout;
     L.bf16 = precision == 1 && L.cin == feature_size && L.cout == feature_size;   // residual-block convolutions only
-    // F = 128 in bf16 has one DMA-fed structure (variant 4) and the register-staged one (0)
-    L.bf16_variant = !L.bf16 ? 0 : feature_size == 256 ? g_bf16_variant : bf16_perm16(g_bf16_variant) ? 4 : 0;
     L.w_off = dev; dev += align_up(L.bf16 ? (size_t)9 * L.cin * L.cout / 2 : packed_weight_floats(L.geom));
     L.b_off = dev; dev += align_up((size_t)L.geom.cout_pad);
     m->layers.push_back(L);
@@ -174,8 +189,7 @@ int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t coun
     const float* k = host_flat + L.flat_off;
     const float* b = k + (size_t)9 * L.cin * L.cout;
     if (L.bf16)
-      pack_conv_weights_bf16_host(k, L.cin, L.cout, bf16_chunk_channels(L.bf16_variant), bf16_perm16(L.bf16_variant),
-                                  reinterpret_cast<uint16_t*>(staged.data() + L.w_off));
+      pack_conv_weights_bf16_host(k, L.cin, L.cout, kBf16ChunkChannels, true, reinterpret_cast<uint16_t*>(staged.data() + L.w_off));
     else
       pack_conv_weights_host(k, L.cin, L.cout, L.geom, staged.data() + L.w_off);
     memcpy(staged.data() + L.b_off, b, sizeof(float) * L.cout);
@@ -189,9 +203,10 @@ int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t coun
 int dsen2_model_workspace_bytes(const dsen2_model* m, int n, int h, int w, size_t* bytes) {
   if (!m || !bytes || n <= 0 || h <= 0 || w <= 0) return fail(DSEN2_ERR_INVALID, "bad argument");
   const size_t pix = (size_t)n * h * w;
-  // fp32: x0 | a | t.   bf16: x0 | a (fp32) | abf, tbf (bf16, half an fp32 tensor each)
-  const size_t full = align_up(pix * m->feat), halves = 2 * align_up(pix * m->feat / 2);
-  *bytes = (align_up(pix * 16) + full + (full > halves ? full : halves)) * sizeof(float);
+  // fp32: x0 | a | t.   bf16: x0 | a (fp32: first convolution's output, last block's output) | hi | lo | t
+  // (hi, lo: the residual stream as two 16-bit planes; t: bf16; each half an fp32 tensor)
+  const size_t full = align_up(pix * m->feat), half = align_up(pix * m->feat / 2);
+  *bytes = (align_up(pix * 16) + full + (m->precision == 1 ? 3 * half : full)) * sizeof(float);
   return DSEN2_OK;
 }
 
@@ -208,7 +223,7 @@ static ConvParams make_params(const float* in, const float* wpk, const float* bi
   p.in = in; p.wpk = wpk; p.bias = bias; p.aux = aux; p.out = out; p.out2 = nullptr;
   p.n = n; p.h = h; p.w = w;
   p.tiles_x = (w + kTile - 1) / kTile; p.tiles_y = (h + kTile - 1) / kTile;
-  p.cout_real = cout_real; p.res_scale = scale; p.stagger = g_body_stagger;
+  p.cout_real = cout_real; p.res_scale = scale;
   return p;
 }
 
@@ -233,42 +248,49 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
   const float* P = m->dev_params;
   const float* skip = m->c60 > 0 ? x60 : x20;    // utils/DSen2Net.py:38,41
 
+  const int abl = m->tune.ablate;
   HIP_TRY(launch_pack_inputs(x10, x20, x60, m->c10, m->c20, m->c60, x0, n, h, w, stream));
   size_t li = 0;
   {
     const Layer& L = m->layers[li++];            // DSen2Net.py:29
-    HIP_TRY(launch_conv3x3(make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f), L.geom, L.epilogue, stream));
+    HIP_TRY(launch_conv3x3(make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f), L.geom, L.epilogue, 0, stream));
   }
-  if (ev_body0 && m->precision != 1) HIP_TRY(hipEventRecord(ev_body0, stream));
-  if (m->precision == 1) {
-    // bf16 operands / fp32 accumulate and residual stream: `a` stays fp32, `t` and the operand copy `abf` of
-    // `a` are bf16 (each half the size of an fp32 activation, together they fit the fp32 path's `t`)
-    void* abf = t;
-    void* tbf = reinterpret_cast<char*>(t) + align_up(pix * m->feat / 2) * sizeof(float);
-    HIP_TRY(launch_f32_to_bf16(a, abf, pix * m->feat, stream));
+  if (m->precision == 1 && m->num_layers > 0) {
+    // bf16 operands, fp32 accumulate, exact fp32 residual stream held as two 16-bit planes (hi = the bf16 operand of
+    // the next convolution, lo = the low halves): conv-A reads hi, conv-B updates (hi, lo) in place; the last
+    // block's conv-B writes plain fp32 for the (fp32) output convolution
+    const size_t half = align_up(pix * m->feat / 2);
+    void* hi = t;
+    void* lo = t + half;
+    void* tbf = t + 2 * half;
+    HIP_TRY(launch_split_f32(a, hi, lo, n, h, w, m->feat, stream));
     if (ev_body0) HIP_TRY(hipEventRecord(ev_body0, stream));
     for (int i = 0; i < m->num_layers; ++i) {
       const Layer& LA = m->layers[li++];
-      ConvParams pa = make_params(reinterpret_cast<const float*>(abf), P + LA.w_off, P + LA.b_off, nullptr,
+      ConvParams pa = make_params(reinterpret_cast<const float*>(hi), P + LA.w_off, P + LA.b_off, nullptr,
                                   reinterpret_cast<float*>(tbf), n, h, w, 0, 0.f);
-      HIP_TRY(launch_conv3x3_body_bf16(pa, m->feat, kEpiRelu, LA.bf16_variant, stream));
+      HIP_TRY(launch_conv3x3_body16w(pa, m->feat, kEpiRelu, abl, stream));
       const Layer& LB = m->layers[li++];
-      ConvParams pb = make_params(reinterpret_cast<const float*>(tbf), P + LB.w_off, P + LB.b_off, a, a, n, h, w, 0, 0.1f);
-      pb.out2 = abf;
-      HIP_TRY(launch_conv3x3_body_bf16(pb, m->feat, kEpiResidual, LB.bf16_variant, stream));
+      const bool last = i + 1 == m->num_layers;
+      ConvParams pb = make_params(reinterpret_cast<const float*>(tbf), P + LB.w_off, P + LB.b_off,
+                                  reinterpret_cast<const float*>(hi), last ? a : reinterpret_cast<float*>(hi), n, h, w, 0, 0.1f);
+      pb.out2 = lo;
+      HIP_TRY(launch_conv3x3_body16w(pb, m->feat, last ? kEpiResidualF32 : kEpiResidual, abl, stream));
     }
-  } else
-  for (int i = 0; i < m->num_layers; ++i) {      // DSen2Net.py:31-32 -> :9-15
-    const Layer& LA = m->layers[li++];
-    HIP_TRY(launch_conv3x3(make_params(a, P + LA.w_off, P + LA.b_off, nullptr, t, n, h, w, 0, 0.f), LA.geom, LA.epilogue, stream));
-    const Layer& LB = m->layers[li++];
-    // in place on the residual stream: every workgroup reads aux and writes out at its own pixels only
-    HIP_TRY(launch_conv3x3(make_params(t, P + LB.w_off, P + LB.b_off, a, a, n, h, w, 0, 0.1f), LB.geom, LB.epilogue, stream));
+  } else {
+    if (ev_body0) HIP_TRY(hipEventRecord(ev_body0, stream));
+    for (int i = 0; i < m->num_layers; ++i) {      // DSen2Net.py:31-32 -> :9-15
+      const Layer& LA = m->layers[li++];
+      HIP_TRY(launch_conv3x3(make_params(a, P + LA.w_off, P + LA.b_off, nullptr, t, n, h, w, 0, 0.f), LA.geom, LA.epilogue, abl, stream));
+      const Layer& LB = m->layers[li++];
+      // in place on the residual stream: every workgroup reads aux and writes out at its own pixels only
+      HIP_TRY(launch_conv3x3(make_params(t, P + LB.w_off, P + LB.b_off, a, a, n, h, w, 0, 0.1f), LB.geom, LB.epilogue, abl, stream));
+    }
   }
   if (ev_body1) HIP_TRY(hipEventRecord(ev_body1, stream));
   {
     const Layer& L = m->layers[li++];            // DSen2Net.py:35,38,41
-    HIP_TRY(launch_conv3x3(make_params(a, P + L.w_off, P + L.b_off, skip, out, n, h, w, m->cout, 0.f), L.geom, L.epilogue, stream));
+    HIP_TRY(launch_conv3x3(make_params(a, P + L.w_off, P + L.b_off, skip, out, n, h, w, m->cout, 0.f), L.geom, L.epilogue, 0, stream));
   }
   return DSEN2_OK;
 }
@@ -302,15 +324,16 @@ int dsen2_model_forward_timed(dsen2_model* m, const float* x10, const float* x20
   return rc;
 }
 
-int dsen2_conv3x3_nhwc(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
-                       float* dev_out, int n, int h, int w, int cin, int cout, int epilogue, float res_scale,
-                       void* stream_) {
+static int conv3x3_nhwc_impl(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
+                             float* dev_out, int n, int h, int w, int cin, int cout, int epilogue, float res_scale,
+                             void* stream_, const Tuning& tune) {
   if (!dev_in || !host_kernel || !host_bias || !dev_out) return fail(DSEN2_ERR_INVALID, "NULL argument");
+  if (epilogue != kEpiRelu && epilogue != kEpiResidual && epilogue != kEpiSkipNCHW) return fail(DSEN2_ERR_INVALID, "epilogue %d", epilogue);
   if (epilogue != kEpiRelu && !dev_aux) return fail(DSEN2_ERR_INVALID, "epilogue %d needs dev_aux", epilogue);
   int rc = check_shape(nullptr, n, h, w);
   if (rc) return rc;
   PackGeom g;
-  if (!conv_pack_geometry(cin, cout, epilogue, &g) || g.cin_pad != cin)
+  if (!conv_pack_geometry(cin, cout, epilogue, tune, &g) || g.cin_pad != cin)
     return fail(DSEN2_ERR_INVALID, "unsupported conv %d->%d epilogue %d", cin, cout, epilogue);
   hipStream_t stream = (hipStream_t)stream_;
   const size_t wf = packed_weight_floats(g);
@@ -321,37 +344,70 @@ int dsen2_conv3x3_nhwc(const float* dev_in, const float* host_kernel, const floa
   HIP_TRY(hipMalloc((void**)&dev, staged.size() * sizeof(float)));
   hipError_t e = hipMemcpy(dev, staged.data(), staged.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess)
-    e = launch_conv3x3(make_params(dev_in, dev, dev + wf, dev_aux, dev_out, n, h, w, cout, res_scale), g, epilogue, stream);
+    e = launch_conv3x3(make_params(dev_in, dev, dev + wf, dev_aux, dev_out, n, h, w, cout, res_scale), g, epilogue, tune.ablate, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFree(dev);
   if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "conv3x3 launch: %s", hipGetErrorString(e));
   return DSEN2_OK;
 }
 
-int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, const float* host_bias,
-                            const float* dev_aux, void* dev_out, void* dev_out2_bf16, int n, int h, int w, int feat,
-                            int epilogue, float res_scale, void* stream_) {
-  if (!dev_in_bf16 || !host_kernel || !host_bias || !dev_out) return fail(DSEN2_ERR_INVALID, "NULL argument");
+int dsen2_conv3x3_nhwc(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
+                       float* dev_out, int n, int h, int w, int cin, int cout, int epilogue, float res_scale,
+                       void* stream) {
+  return conv3x3_nhwc_impl(dev_in, host_kernel, host_bias, dev_aux, dev_out, n, h, w, cin, cout, epilogue, res_scale,
+                           stream, default_tuning());
+}
+
+int dsen2_conv3x3_nhwc_ref(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
+                           float* dev_out, int n, int h, int w, int cin, int cout, int epilogue, float res_scale,
+                           void* stream) {
+  Tuning ref;                 // the one-tile-per-workgroup kernels of conv3x3_mfma.hip for every layer shape
+  ref.body_variant = 0;
+  ref.out_variant = 0;
+  return conv3x3_nhwc_impl(dev_in, host_kernel, host_bias, dev_aux, dev_out, n, h, w, cin, cout, epilogue, res_scale,
+                           stream, ref);
+}
+
+int dsen2_split_f32(const float* dev_in, void* dev_hi, void* dev_lo, int n, int h, int w, int c, void* stream) {
+  if (!dev_in || !dev_hi || !dev_lo || n < 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 != 0 || c > 512)
+    return fail(DSEN2_ERR_INVALID, "bad argument (c must be a multiple of 8, at most 512)");
+  if (n == 0) return DSEN2_OK;
+  HIP_TRY(launch_split_f32(dev_in, dev_hi, dev_lo, n, h, w, c, (hipStream_t)stream));
+  return DSEN2_OK;
+}
+
+int dsen2_join_f32(const void* dev_hi, const void* dev_lo, float* dev_out, int n, int h, int w, int c, void* stream) {
+  if (!dev_out || !dev_hi || !dev_lo || n < 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 != 0 || c > 512)
+    return fail(DSEN2_ERR_INVALID, "bad argument (c must be a multiple of 8, at most 512)");
+  if (n == 0) return DSEN2_OK;
+  HIP_TRY(launch_join_f32(dev_hi, dev_lo, dev_out, n, h, w, c, (hipStream_t)stream));
+  return DSEN2_OK;
+}
+
+int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, const float* host_bias, void* dev_res_hi,
+                            void* dev_res_lo, void* dev_out, int n, int h, int w, int feat, int epilogue,
+                            float res_scale, void* stream_) {
+  if (!dev_in_bf16 || !host_kernel || !host_bias) return fail(DSEN2_ERR_INVALID, "NULL argument");
   if (feat != 128 && feat != 256) return fail(DSEN2_ERR_INVALID, "feat %d unsupported", feat);
-  if (epilogue == kEpiResidual && (!dev_aux || !dev_out2_bf16)) return fail(DSEN2_ERR_INVALID, "residual needs aux and out2");
-  if (epilogue != kEpiRelu && epilogue != kEpiResidual) return fail(DSEN2_ERR_INVALID, "epilogue %d", epilogue);
+  if (epilogue != kEpiRelu && epilogue != kEpiResidual && epilogue != kEpiResidualF32) return fail(DSEN2_ERR_INVALID, "epilogue %d", epilogue);
+  if (epilogue != kEpiRelu && (!dev_res_hi || !dev_res_lo)) return fail(DSEN2_ERR_INVALID, "residual epilogue needs the hi and lo planes");
+  if (epilogue != kEpiResidual && !dev_out) return fail(DSEN2_ERR_INVALID, "dev_out is NULL");
   int rc = check_shape(nullptr, n, h, w);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   const size_t wn = (size_t)9 * feat * feat;
   std::vector<uint16_t> wb(wn);
-  const int variant = feat == 256 ? g_bf16_variant : bf16_perm16(g_bf16_variant) ? 4 : 0;
-  pack_conv_weights_bf16_host(host_kernel, feat, feat, bf16_chunk_channels(variant), bf16_perm16(variant), wb.data());
+  pack_conv_weights_bf16_host(host_kernel, feat, feat, kBf16ChunkChannels, true, wb.data());
   char* dev = nullptr;
   HIP_TRY(hipMalloc((void**)&dev, wn * 2 + feat * sizeof(float)));
   hipError_t e = hipMemcpy(dev, wb.data(), wn * 2, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(dev + wn * 2, host_bias, feat * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     ConvParams p = make_params(reinterpret_cast<const float*>(dev_in_bf16), reinterpret_cast<const float*>(dev),
-                               reinterpret_cast<const float*>(dev + wn * 2), dev_aux, reinterpret_cast<float*>(dev_out),
-                               n, h, w, 0, res_scale);
-    p.out2 = dev_out2_bf16;
-    e = launch_conv3x3_body_bf16(p, feat, epilogue, variant, stream);
+                               reinterpret_cast<const float*>(dev + wn * 2), reinterpret_cast<const float*>(dev_res_hi),
+                               reinterpret_cast<float*>(epilogue == kEpiResidual ? dev_res_hi : dev_out), n, h, w, 0, res_scale);
+    p.out2 = dev_res_lo;
+    e = launch_conv3x3_body16w(p, feat, epilogue, default_tuning().ablate, stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFree(dev);
@@ -371,12 +427,18 @@ int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, c
   hipStream_t stream = (hipStream_t)stream_;
   const float* P = m->dev_params;
   ConvParams p = make_params(dev_in, P + L.w_off, P + L.b_off, dev_aux, dev_out, n, h, w, 0, 0.1f);
-  // bf16 model: dev_in is bf16 NHWC; kEpiRelu writes bf16 to dev_out; kEpiResidual writes fp32 to dev_out and its
-  // bf16 copy right behind it (dev_out must then hold 1.5 fp32 tensors)
-  if (L.bf16 && L.epilogue == kEpiResidual) p.out2 = dev_out + (size_t)n * h * w * m->feat;
+  int epi = L.epilogue;
+  if (L.bf16 && L.epilogue == kEpiResidual) {
+    // dev_aux = hi plane followed by lo plane (one fp32-sized buffer), updated in place; the last block's layer
+    // writes fp32 to dev_out instead
+    const bool last = layer == 2 * m->num_layers;
+    p.out2 = reinterpret_cast<char*>(const_cast<float*>(dev_aux)) + (size_t)n * h * w * m->feat * 2;
+    p.out = last ? dev_out : const_cast<float*>(dev_aux);
+    epi = last ? kEpiResidualF32 : kEpiResidual;
+  }
+  const int abl = m->tune.ablate;
   auto launch = [&]() -> hipError_t {
-    return L.bf16 ? launch_conv3x3_body_bf16(p, m->feat, L.epilogue, L.bf16_variant, stream)
-                  : launch_conv3x3(p, L.geom, L.epilogue, stream);
+    return L.bf16 ? launch_conv3x3_body16w(p, m->feat, epi, abl, stream) : launch_conv3x3(p, L.geom, L.epilogue, abl, stream);
   };
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));

@@ -1,0 +1,608 @@
+// conv3x3_body16w.hip — bf16-operand F->F 3x3 'same' convolution (F = 128 or 256) of the residual blocks
+// (utils/DSen2Net.py:9-15 with precision = 1): v_mfma_f32_16x16x32_bf16 fed by LDS-DMA, WIDE pixel tile.
+//
+// Round-1's kernel (16x16 pixels x 128 channels per item) spent its time in the CU's vector-memory path, not
+// in the matrix pipe (profiles/r01_ablation.md): per 151 MFLOP item it pulled 576 KiB of weights + 162 KiB of
+// input through L1 into LDS and, for conv-B, pushed 24 store instructions per lane back through the same path.
+// This kernel changes the three ratios that set that traffic:
+//
+//   1. ITEM = 16 rows x 32 columns of pixels x 128 output channels.  A weight chunk now feeds 512 pixels instead
+//      of 256: L2->LDS bytes per MFMA fall by 40 % (weights 288 KiB + input 153 KiB per 151 MFLOP), and a wave's
+//      64-channel x 128-pixel tile (4 x 8 accumulators) needs 12 ds_read_b128 per 32 MFMAs instead of 16.
+//   2. STEP = (tap, 32 input channels) = one MFMA k-step: an 8 KiB weight chunk, so the weight ring holds 8 chunks
+//      and the stream runs SEVEN steps ahead.  vmcnt retires in issue order, so a wave that waits for a fresh DMA
+//      also waits for every older store; with a seven-step lead the waits of an item's first five steps target
+//      DMAs issued BEFORE the previous item's epilogue and count its loads and stores as younger
+//      (vmcnt(63)): the stores get 2.5 us to drain instead of one step.
+//   3. RESIDUAL STREAM AS TWO 16-BIT PLANES (conv-B).  The fp32 residual value u is kept as
+//      hi = (u + 0x8000) >> 16 (its bf16 rounding, ties away from zero) and lo = u & 0xffff: the pair restores u bit
+//      for bit (u = ((hi - (lo >> 15)) << 16) | lo, all mod 2^16 / 2^32), `hi` IS the next convolution's bf16
+//      operand, so the separate bf16 copy of round 1 is gone.
+//   4. BLOCKED 16-BIT TENSORS.  The bf16 activations (t, hi) and the lo plane are stored [n][C/8][h][w][8]: an
+//      8-channel block is a plane of 16-byte pixels.  The MFMA result gives a lane 8 channels of ONE pixel and its
+//      neighbour lane the next pixel; channels-last (pixels 512 B apart) makes every 16-byte access its own cache
+//      line, and the CU's texture addresser then spends a cycle per lane — ~80 cycles per 1-KiB store instruction,
+//      more addresser time per conv-B item than the item has MFMA cycles.  Blocked, the 16 lanes of a pixel-row
+//      segment read or write 256 contiguous bytes, and the input DMA's 64 lanes read runs of a halo row.
+//
+// Kept from round 1: weights as the MFMA's A operand with the row permutation that gives a lane 8 consecutive
+// channels of one pixel (pack_conv_weights_bf16_host, perm16), the [channel group][pixel slot][16 B] input
+// layout (conflict-free ds_read_b128), DMAs from inline asm with hand-counted vmcnt, persistent XCD-contiguous
+// item walk, rotated item loop.  Bias is the accumulators' initial value.
+#include <type_traits>
+
+#include "dsen2_internal.h"
+
+namespace dsen2 {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TH = 16, TW = 32;             // output pixels per item
+constexpr int HH = TH + 2, HW = TW + 2;     // halo tile 18 x 34
+constexpr int HALO = HH * HW;               // 612 pixel slots in use
+constexpr int QS = 640;                     // slots per channel-group row: 10 DMA blocks of 64, = 0 mod 16
+constexpr int NG = 4;                       // 16-byte channel groups per pixel and step (32 bf16 channels)
+constexpr int IN_BYTES = NG * QS * 16;      // one input chunk buffer (40,960 B)
+constexpr int IN_ROUNDS = 5;                // DMA rounds per wave and chunk: wave = (group, even/odd blocks)
+constexpr int WCH_BYTES = 32 * 128 * 2;     // one weight chunk: [4 k-groups][128 rows][16 B] = 8 KiB
+constexpr int RING = 8;                     // weight ring slots
+constexpr int LEAD = RING - 1;              // chunk c + LEAD is issued in step c
+constexpr int THREADS = 512;                // 8 waves: (channel half) x (4-row strip)
+constexpr int MB = 4, PB = 8;               // per wave: 4 x 16 channels, 8 x 16 pixels (4 rows x 2 column halves)
+constexpr size_t LDS_BYTES = (size_t)2 * IN_BYTES + (size_t)RING * WCH_BYTES + 256 * 4;
+static_assert(QS >= HALO && QS % 16 == 0 && QS == 64 * 2 * IN_ROUNDS, "input chunk geometry");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// input DMA rounds issued in the step of tap t (before that step's weight DMA): all five within taps 0-2, so the
+// wait at the end of tap 7 (which retires everything up to tap 2's weight DMA) publishes the whole chunk
+constexpr int rounds_in_tap(int t) { return t < 2 ? 2 : t == 2 ? 1 : 0; }
+constexpr int first_round_of_tap(int t) { return t == 0 ? 0 : t == 1 ? 2 : 4; }
+// vector-memory operations a wave issues AFTER the weight DMA of step s-5 up to the end of step s (tap t): the
+// weight DMAs of steps s-4..s and those steps' input rounds.  vmcnt(N) at the end of step s therefore retires the
+// wave's piece of weight chunk s+2 (issued in step s-5) and everything older.
+constexpr int younger_ops(int t, bool has_w, bool has_in) {
+  int n = 0;
+  for (int j = 0; j < 5; ++j) n += (has_w ? 1 : 0) + (has_in ? rounds_in_tap((t - j + 9) % 9) : 0);
+  return n;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA wave instruction: 1 KiB global -> LDS, LDS address = m0v + 16 * lane, a lane whose offset is out of the
+// descriptor's range writes zeros.  hipcc reserves M0 (it rejects "m0" in a clobber list as undefined behaviour), so
+// the statement saves and restores it: the compiler's own uses of M0 never see the DMA's value.
+__device__ __forceinline__ void lds_dma(unsigned m0v, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+  unsigned saved_m0;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(saved_m0) : "s"(m0v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// ---- the 16 + 16 bit split of an fp32 value (see the header): two values per call ----
+__device__ __forceinline__ void split2(unsigned u0, unsigned u1, unsigned& hi, unsigned& lo) {
+  lo = __builtin_amdgcn_perm(u1, u0, 0x05040100u);                    // [u1.lo16 : u0.lo16]
+  const unsigned top = __builtin_amdgcn_perm(u1, u0, 0x07060302u);    // [u1.hi16 : u0.hi16]
+  const u16x2 r = __builtin_bit_cast(u16x2, top) + (__builtin_bit_cast(u16x2, lo) >> (unsigned short)15);
+  hi = __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ void join2(unsigned hi, unsigned lo, unsigned& u0, unsigned& u1) {
+  const u16x2 t = __builtin_bit_cast(u16x2, hi) - (__builtin_bit_cast(u16x2, lo) >> (unsigned short)15);
+  const unsigned top = __builtin_bit_cast(unsigned, t);
+  u0 = __builtin_amdgcn_perm(top, lo, 0x05040100u);
+  u1 = __builtin_amdgcn_perm(top, lo, 0x07060302u);
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+}  // namespace
+
+// EPI: kEpiRelu       out (bf16 NHWC) = relu(conv + bias)                                   conv-A
+//      kEpiResidual   (aux, out2) = split(join(aux, out2) + res_scale * (conv + bias))      conv-B, in place on the planes
+//      kEpiResidualF32  out (fp32 NHWC) = join(aux, out2) + res_scale * (conv + bias)       conv-B of the last block
+// CINW = 32-bit words per input pixel (= F / 2).  ABL (diagnostic builds): timing-only ablation mask
+// (1 no stores, 2 no residual loads, 4 no weight stream, 8 no input stream, 16 no barriers).
+template <int CINW, int COUT, int EPI, int ABL>
+__global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvParams p, const int n_items) {
+  constexpr int NCC = CINW / 16;              // 32-channel chunks
+  constexpr int NCHUNK = NCC * 9;
+  constexpr int NS = COUT / 128;
+  constexpr bool kW = !(ABL & 4), kIn = !(ABL & 8);
+  constexpr bool kRes = EPI != kEpiRelu;
+  // vector-memory operations of one epilogue (per wave): 16 groups of 8 channels x (stores + residual loads)
+  constexpr int E_OPS = ((ABL & 1) ? 0 : (EPI == kEpiRelu ? 16 : 32)) + (kRes && !(ABL & 2) ? 32 : 0);
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const in_s = reinterpret_cast<char*>(smem);                       // [2][4][QS][16 B]
+  char* const w_s = in_s + 2 * IN_BYTES;                                  // [RING][4 k-groups][128 rows][16 B]
+  float* const bias_s = reinterpret_cast<float*>(w_s + RING * WCH_BYTES);   // [COUT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1;                 // 64-channel half of the slab
+  const int wp = wave >> 1;                // rows 4*wp .. 4*wp+3 of the tile
+  const int l15 = lane & 15;
+  const int q4 = lane >> 4;
+
+  // persistent schedule: logical ids remapped so that each XCD (blockIdx % 8) walks a contiguous run of items
+  const int G = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  if (lid >= n_items) return;
+  const int my_items = (n_items - lid + G - 1) / G;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const size_t img_pix = (size_t)p.h * p.w;
+
+  struct Tile { int img, ty0, tx0, slab; };
+  auto tile_of = [&](int item) -> Tile {
+    const int tile = item / NS;
+    const int img = tile / tiles_per_img;
+    const int trem = tile - img * tiles_per_img;
+    const int tyi = trem / p.tiles_x;
+    return Tile{img, tyi * TH, (trem - tyi * p.tiles_x) * TW, item - tile * NS};
+  };
+
+  // ---- the two DMA streams ----
+  const unsigned lds_in = lds_address(in_s), lds_w = lds_address(w_s);
+  const int dq = wave & 3, dhalf = wave >> 2;      // input DMA role of this wave: channel group, even/odd 64-slot blocks
+  __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (unsigned)(NS * NCHUNK * WCH_BYTES), 0x00020000);
+  const unsigned in_plane_bytes = (unsigned)(img_pix * 16);   // one 8-channel block of one image
+  int st_y0 = 0, st_x0 = 0;                        // origin of the tile being staged
+  auto set_stage_item = [&](int item) {
+    const Tile t = tile_of(item);
+    in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(const_cast<float*>(p.in)) + (size_t)t.img * img_pix * CINW * 4, 0,
+        (unsigned)(img_pix * CINW * 4), 0x00020000);
+    st_y0 = t.ty0;
+    st_x0 = t.tx0;
+  };
+  // round r (0-4) of input chunk cc into buffer `buf`: 64 halo pixels of channel group dq
+  auto issue_in = [&](int buf, int r, int cc) {
+    // the per-lane offset is recomputed per round from an opaque copy of the lane id (a dozen VALU operations): ten
+    // loop-invariant registers for the five rounds do not fit beside 128 accumulators
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int b = 2 * r + dhalf;
+    const int hp = 64 * b + ln;
+    const int hy = (hp * 1928) >> 16, hx = hp - hy * HW;      // hp / 34 for hp < 640
+    const int gy = st_y0 - 1 + hy, gx = st_x0 - 1 + hx;
+    const bool inb = hp < HALO && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
+    // blocked layout: 8-channel block (4*cc + dq) is a plane of 16-byte pixels, so the 64 lanes of a round read
+    // runs of consecutive addresses (one run per halo row).  Out of range (any offset >= 2^31) reads zeros = the
+    // convolution's padding; no branch
+    const unsigned voff = ((unsigned)(__umul24(gy, p.w) + gx) * 16u + in_plane_bytes * (unsigned)dq) | (inb ? 0u : 0x80000000u);
+    const unsigned m0v = lds_in + buf * IN_BYTES + (dq * QS + 64 * b) * 16;
+    const unsigned so = (unsigned)(4 * cc) * in_plane_bytes;
+    lds_dma(m0v, voff, in_rsrc, so);
+  };
+  // the next weight chunk of this workgroup's stream (8 wave instructions of 1 KiB, one per wave) into the next
+  // ring slot; the stream runs over item boundaries and, past the last item, wraps to the first one (harmless)
+  int wl_item = lid, wl_chunk = 0, wl_slot = 0;
+  const unsigned w_voff = lane * 16;
+  auto issue_w = [&]() {
+    const unsigned so = (unsigned)(((wl_item % NS) * NCHUNK + wl_chunk) * WCH_BYTES + wave * 1024);
+    const unsigned m0v = lds_w + wl_slot * WCH_BYTES + wave * 1024;
+    lds_dma(m0v, w_voff, w_rsrc, so);
+    if (++wl_chunk == NCHUNK) {
+      wl_chunk = 0;
+      wl_item = wl_item + G < n_items ? wl_item + G : lid;
+    }
+    wl_slot = wl_slot == RING - 1 ? 0 : wl_slot + 1;
+  };
+
+  // ---- per-lane operand addresses (bytes) ----
+  // B operand (pixels): lane -> pixel column l15 of a 16-pixel row segment, channel group q4 of the chunk
+  // A operand (weights): [k-group q4][row = wn*64 + 16*mb + l15][16 B]
+  const int x_lane = (q4 * QS + (4 * wp) * HW + l15) * 16;
+  const int w_lane = (q4 * 128 + wn * 64 + l15) * 16;
+
+  // ---- prologue: first item's input chunk 0, weight chunks 0 .. LEAD-1 ----
+  set_stage_item(lid);
+  if constexpr (kIn) {
+#pragma unroll
+    for (int r = 0; r < IN_ROUNDS; ++r) issue_in(0, r, 0);
+  }
+  if constexpr (kW) {
+#pragma unroll
+    for (int c = 0; c < LEAD; ++c) issue_w();
+  }
+  if (tid < COUT) bias_s[tid] = p.bias[tid];
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  f32x4 w_cur[MB], x_cur[PB];
+  int mf_slot = 0;
+  auto read_x = [&](f32x4 (&xf)[PB], const char* ib, int tap) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const char* xp_ = ib + x_lane + (dy * HW + dx) * 16;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) xf[pb] = *reinterpret_cast<const f32x4*>(xp_ + ((pb >> 1) * HW + 16 * (pb & 1)) * 16);
+  };
+  auto read_w1 = [&](int mb, const char* wb) -> f32x4 {
+    return *reinterpret_cast<const f32x4*>(wb + w_lane + mb * 256);
+  };
+
+  f32x4 acc[MB][PB];
+
+  // ---- epilogue of one item: lane = pixel (row 4*wp + (pb>>1), column 16*(pb&1) + l15), group (pr, pb) =
+  // 8 consecutive channels slab*128 + wn*64 + 32*pr + 8*q4 held by accumulators 2*pr and 2*pr+1 ----
+  auto epilogue = [&](int item, bool valid) {
+    const Tile t = tile_of(item);
+    const int ch8 = t.slab * 128 + wn * 64 + 8 * q4;
+    const int ex = t.tx0 + l15, ey = t.ty0 + 4 * wp;
+    // Byte offset of group (pr, pb) inside its image, branch-free.  16-bit tensors are BLOCKED: 8-channel block k of
+    // an image is a plane [h][w] of 16-byte pixels, so the 16 lanes of a pixel-row segment touch 256 contiguous
+    // bytes and the texture addresser coalesces them four lanes at a time (with channels-last pixels 512 B apart it
+    // spent one cycle per lane: 80 cycles per store instruction).  A pixel outside the image (ragged tile; the dummy
+    // epilogue before the first item) gets bit 31 set = out of the descriptor's range: every load and store is
+    // always ISSUED, which is what the hand-counted waits of the next item's first steps rely on.
+    const unsigned blk0 = (unsigned)(ch8 >> 3);                       // + 4*pr
+    const unsigned base_pix = (unsigned)(ey * p.w + ex);
+    const unsigned bad_all = valid ? 0u : 0x80000000u;
+    auto bad_of = [&](int pb) -> unsigned {
+      const int row = ey + (pb >> 1), col = ex + 16 * (pb & 1);
+      return bad_all | (row < p.h ? 0u : 0x80000000u) | (col < p.w ? 0u : 0x80000000u);
+    };
+    auto plane_off = [&](int pr, int pb) -> unsigned {                // 16-bit blocked tensors
+      return (((blk0 + 4u * pr) * (unsigned)img_pix + base_pix + (unsigned)((pb >> 1) * p.w + 16 * (pb & 1))) * 16u & 0x7fffffffu) | bad_of(pb);
+    };
+    auto nhwc_f32_off = [&](int pr, int pb) -> unsigned {             // fp32 channels-last tensor (kEpiResidualF32)
+      return (((base_pix + (unsigned)((pb >> 1) * p.w + 16 * (pb & 1))) * (unsigned)COUT + (unsigned)(ch8 + 32 * pr)) * 4u & 0x7fffffffu) | bad_of(pb);
+    };
+    const size_t img_elems = img_pix * COUT;
+    if constexpr (EPI == kEpiRelu) {
+      const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char*>(p.out) + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          f32x4 v0 = acc[2 * pr][pb], v1 = acc[2 * pr + 1][pb];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0[e] = fmaxf(v0[e], 0.f);
+            v1[e] = fmaxf(v1[e], 0.f);
+          }
+          const u32x4 hv = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+          if constexpr (!(ABL & 1))
+            __builtin_amdgcn_raw_buffer_store_b128(hv, out_rsrc, plane_off(pr, pb), 0, 0);
+          else
+            asm volatile("" ::"v"(hv));
+          if (pr == 1) __builtin_amdgcn_sched_barrier(0);     // bounds the packed values in flight (registers)
+        }
+    } else {
+      const auto hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char*>(const_cast<float*>(p.aux)) + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
+      const auto lo_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char*>(p.out2) + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
+      const auto f32_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char*>(p.out) + (EPI == kEpiResidualF32 ? (size_t)t.img * img_elems * 4 : 0), 0,
+          EPI == kEpiResidualF32 ? (unsigned)(img_elems * 4) : 0, 0x00020000);
+      // pass j = tile row 4*wp + j: 4 groups (2 column halves x 2 channel pairs).  Residual loads run two passes
+      // ahead of the stores in issue order (L0 L1 | C0 L2 S0 | C1 L3 S1 | C2 S2 | C3 S3): only the last pass's
+      // loads are younger than a store (pass 0's), so vmcnt's in-order retirement exposes one store drain, not four
+      u32x4 rh[4][4], rl[4][4];
+      auto load_pass = [&](int j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int pb = 2 * j + (g >> 1), pr = g & 1;
+          if constexpr (!(ABL & 2)) {
+            const unsigned eo = plane_off(pr, pb);
+            rh[j][g] = __builtin_amdgcn_raw_buffer_load_b128(hi_rsrc, eo, 0, 0);
+            rl[j][g] = __builtin_amdgcn_raw_buffer_load_b128(lo_rsrc, eo, 0, 0);
+          } else {
+            rh[j][g] = rl[j][g] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          }
+        }
+      };
+      auto finish_pass = [&](int j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int pb = 2 * j + (g >> 1), pr = g & 1;
+          const f32x4 c0 = acc[2 * pr][pb], c1 = acc[2 * pr + 1][pb];
+          const float cv[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+          unsigned ov[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            unsigned u0, u1;
+            join2(rh[j][g][k], rl[j][g][k], u0, u1);
+            // x + 0.1 * (conv + b): two roundings like keras (-ffp-contract=off)
+            ov[2 * k] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, u0) + cv[2 * k] * p.res_scale);
+            ov[2 * k + 1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, u1) + cv[2 * k + 1] * p.res_scale);
+          }
+          if constexpr (EPI == kEpiResidual) {
+            const unsigned eo = plane_off(pr, pb);
+            u32x4 oh, ol;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              unsigned h_, l_;
+              split2(ov[2 * k], ov[2 * k + 1], h_, l_);
+              oh[k] = h_;
+              ol[k] = l_;
+            }
+            if constexpr (!(ABL & 1)) {
+              __builtin_amdgcn_raw_buffer_store_b128(oh, hi_rsrc, eo, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(ol, lo_rsrc, eo, 0, 0);
+            } else {
+              asm volatile("" ::"v"(oh), "v"(ol));
+            }
+          } else {
+            const u32x4 o0 = {ov[0], ov[1], ov[2], ov[3]}, o1 = {ov[4], ov[5], ov[6], ov[7]};
+            const unsigned eo = nhwc_f32_off(pr, pb);
+            if constexpr (!(ABL & 1)) {
+              // immediate soffset only (store-data hazard of buffer_store_dwordx4 with an SGPR soffset, experiments/README.md)
+              __builtin_amdgcn_raw_buffer_store_b128(o0, f32_rsrc, eo, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(o1, f32_rsrc, eo + 16u, 0, 0);
+            } else {
+              asm volatile("" ::"v"(o0), "v"(o1));
+            }
+          }
+        }
+      };
+      load_pass(0);
+      load_pass(1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 2 < 4) load_pass(j + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        finish_pass(j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // Rotated item loop: iteration `it` first writes out item it-1 (the first iteration issues the same loads and
+  // stores with out-of-range offsets, so every path into an item's first steps has issued E_OPS operations),
+  // then runs item `it`'s NCHUNK steps; one extra iteration writes the last item.
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) acc[mb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int it = 0; it <= my_items; ++it) {
+    epilogue(it > 0 ? lid + (it - 1) * G : lid, it > 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it == my_items) break;
+    const int item = lid + it * G;
+    const bool have_next_item = it + 1 < my_items;
+    {
+      // accumulators start at the bias of their channels: acc[2*pr + e][.][r] <-> channel ch8 + 32*pr + 4*e + r
+      const int ch8 = (item % NS) * 128 + wn * 64 + 8 * q4;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + ch8 + 32 * (mb >> 1) + 4 * (mb & 1));
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) acc[mb][pb] = b;
+      }
+    }
+    // fragments of the item's first step (not prefetched across the epilogue: it needs the registers)
+    {
+      const char* const wb = w_s + mf_slot * WCH_BYTES;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) w_cur[mb] = read_w1(mb, wb);
+      read_x(x_cur, in_s, 0);
+    }
+
+    // ONE copy of the nine-step body for every input chunk (a separate copy for the item's first chunk makes the
+    // register allocator permute all 32 accumulators between the two copies and spill); the first chunk's five
+    // epilogue-aware waits are a scalar branch
+    auto do_cc = [&](const int cc) {
+      const char* const ib = in_s + (cc & 1) * IN_BYTES;
+      const char* const ib_next = in_s + ((cc + 1) & 1) * IN_BYTES;
+      // staged into ib_next during this cc: (this item, cc+1), or on the last cc the NEXT item's chunk 0 (on the
+      // very last item: its own chunk 0 again, which nobody reads — the operation count stays the same)
+      const bool last_cc = cc == NCC - 1;
+      const int in_cc = last_cc ? 0 : cc + 1;
+      if (last_cc && have_next_item) set_stage_item(item + G);
+      auto step = [&](auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value;
+        const int nx_slot = mf_slot == RING - 1 ? 0 : mf_slot + 1;
+        const char* const wb_nx = w_s + nx_slot * WCH_BYTES;
+        // this step's DMAs: input rounds first, then the weight chunk LEAD steps ahead
+        if constexpr (kIn) {
+#pragma unroll
+          for (int r = 0; r < rounds_in_tap(tap); ++r) issue_in((cc + 1) & 1, first_round_of_tap(tap) + r, in_cc);
+        }
+        if constexpr (kW) issue_w();
+        // Fragments of the NEXT step are read into the registers of this one as soon as their last MFMA has
+        // issued: pixel fragment pb after the last channel block's MFMA on it, weight fragment mb after its 8 MFMAs —
+        // no second register set.  (An item's last step reads the next item's first fragments too; they are read
+        // again after the epilogue, which needs the registers.)
+        const char* const xb_nx = (tap < 8 ? ib : ib_next) + x_lane + ((tap < 8 ? (tap + 1) / 3 : 0) * HW + (tap < 8 ? (tap + 1) % 3 : 0)) * 16;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) {
+            acc[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w_cur[mb]),
+                                                                  __builtin_bit_cast(bf16x8, x_cur[pb]),
+                                                                  acc[mb][pb], 0, 0, 0);
+            if (mb == MB - 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              x_cur[pb] = *reinterpret_cast<const f32x4*>(xb_nx + ((pb >> 1) * HW + 16 * (pb & 1)) * 16);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          w_cur[mb] = read_w1(mb, wb_nx);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mf_slot = nx_slot;
+        __builtin_amdgcn_sched_barrier(0);
+        // retire this wave's piece of the weight chunk two steps ahead (issued five steps ago) and everything
+        // older; in an item's first five steps the previous epilogue's loads and stores are younger than that
+        // chunk and stay in flight
+        constexpr int kN = younger_ops(tap, kW, kIn);
+        constexpr int kNE = kN + E_OPS < 63 ? kN + E_OPS : 63;
+        if constexpr (tap < 5 && kNE != kN) {
+          // vmcnt(kNE) in the item's first chunk, vmcnt(kN) otherwise.  The scalar branch lives inside ONE asm
+          // statement so that the nine-step body stays a single basic block (split into blocks, hipcc's register
+          // allocator shuffles the accumulators between them and spills into the DMA-counted vmcnt stream).
+          asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Ldsen2_w%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Ldsen2_e%=\n"
+                       ".Ldsen2_w%=:\n\ts_waitcnt vmcnt(%2)\n.Ldsen2_e%=:"
+                       ::"s"(cc), "n"(kN), "n"(kNE) : "memory", "scc");
+        } else {
+          wait_vmcnt<kN>();
+        }
+        if constexpr (!(ABL & 16)) __syncthreads();
+      };
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{});
+      step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{});
+      step(std::integral_constant<int, 7>{});
+      step(std::integral_constant<int, 8>{});
+    };
+#pragma unroll 1
+    for (int cc = 0; cc < NCC; ++cc) do_cc(cc);
+  }
+  wait_vmcnt<0>();       // no DMA may still be writing this workgroup's LDS when it is released
+}
+
+template <int CINW, int COUT, int EPI, int ABL = 0>
+static hipError_t launch_body16w_one(ConvParams p, hipStream_t stream) {
+  auto kern = conv3x3_body16w_kernel<CINW, COUT, EPI, ABL>;
+  static bool attr_set[64] = {};
+  static int cus[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    attr_set[dev] = true;
+  }
+  // per-image buffer descriptors: byte offsets below 2^31 (bit 31 marks a pixel outside the image)
+  if ((size_t)p.h * p.w * COUT >= ((size_t)1 << 29)) return hipErrorInvalidValue;
+  p.tiles_x = (p.w + TW - 1) / TW;
+  p.tiles_y = (p.h + TH - 1) / TH;
+  const long long items = (long long)p.n * p.tiles_x * p.tiles_y * (COUT / 128);
+  if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;
+  const int grid = (int)(items < cus[dev] ? items : cus[dev]);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, stream, p, (int)items);
+  return hipGetLastError();
+}
+
+template <int F>
+static hipError_t launch_body16w_feat(const ConvParams& p, int epilogue, int ablate, hipStream_t stream) {
+#ifdef DSEN2_DIAG
+#define DSEN2_ABL(M)                                                                                         \
+  if (ablate == M)                                                                                           \
+    return epilogue == kEpiRelu       ? launch_body16w_one<F / 2, F, kEpiRelu, M>(p, stream)                  \
+           : epilogue == kEpiResidual ? launch_body16w_one<F / 2, F, kEpiResidual, M>(p, stream)              \
+                                      : launch_body16w_one<F / 2, F, kEpiResidualF32, M>(p, stream);
+  DSEN2_ABL(1) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31)
+#undef DSEN2_ABL
+#endif
+  if (ablate != 0) return hipErrorInvalidValue;
+  if (epilogue == kEpiRelu) return launch_body16w_one<F / 2, F, kEpiRelu>(p, stream);
+  if (epilogue == kEpiResidual) return launch_body16w_one<F / 2, F, kEpiResidual>(p, stream);
+  if (epilogue == kEpiResidualF32) return launch_body16w_one<F / 2, F, kEpiResidualF32>(p, stream);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv3x3_body16w(const ConvParams& p, int feat, int epilogue, int ablate, hipStream_t stream) {
+  if (epilogue != kEpiRelu && (!p.aux || !p.out2)) return hipErrorInvalidValue;
+  if (feat == 128) return launch_body16w_feat<128>(p, epilogue, ablate, stream);
+  if (feat == 256) return launch_body16w_feat<256>(p, epilogue, ablate, stream);
+  return hipErrorInvalidValue;
+}
+
+// ---- fp32 channels-last tensor <-> blocked (hi, lo) planes (after the first convolution; test hooks) ----
+// One thread per (pixel, 8-channel block).  Threads of a workgroup cover 32 consecutive pixels x all blocks of an
+// image, block index fastest on the fp32 side (32-byte pieces of one pixel's 4*C bytes) and pixel index fastest
+// on the plane side, through LDS so that both sides are written / read in contiguous runs.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void split_join_kernel(float* __restrict__ f32, uint4* __restrict__ hi, uint4* __restrict__ lo,
+                                                         int img_pix, int nblk, long long total_groups) {
+  // a group = 32 consecutive pixels of one image x all nblk blocks; LDS: [32 px][nblk][8 floats] (+1 float4 pad per pixel)
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int pitch = nblk * 8 + 4;
+  const int groups_per_img = (img_pix + 31) / 32;
+  for (long long g = blockIdx.x; g < total_groups; g += gridDim.x) {
+    const long long img = g / groups_per_img;
+    const int p0 = (int)(g - img * groups_per_img) * 32;
+    const int npx = min(32, img_pix - p0);
+    float* const src = f32 + ((size_t)img * img_pix + p0) * (size_t)(nblk * 8);
+    uint4* const hi_img = hi + (size_t)img * nblk * img_pix;
+    uint4* const lo_img = lo + (size_t)img * nblk * img_pix;
+    if constexpr (SPLIT) {
+      for (int i = threadIdx.x; i < npx * nblk * 2; i += blockDim.x) {           // float4 pieces, channel-fastest
+        const int px = i / (nblk * 2), q = i - px * (nblk * 2);
+        *reinterpret_cast<f32x4*>(tile + px * pitch + q * 4) = *reinterpret_cast<const f32x4*>(src + (size_t)px * nblk * 8 + q * 4);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < npx * nblk; i += blockDim.x) {               // (block, pixel), pixel-fastest
+        const int blk = i / npx, px = i - blk * npx;
+        const unsigned* v = reinterpret_cast<const unsigned*>(tile + px * pitch + blk * 8);
+        unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+        split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1); split2(v[4], v[5], h2, l2); split2(v[6], v[7], h3, l3);
+        hi_img[(size_t)blk * img_pix + p0 + px] = make_uint4(h0, h1, h2, h3);
+        lo_img[(size_t)blk * img_pix + p0 + px] = make_uint4(l0, l1, l2, l3);
+      }
+      __syncthreads();
+    } else {
+      for (int i = threadIdx.x; i < npx * nblk; i += blockDim.x) {
+        const int blk = i / npx, px = i - blk * npx;
+        const uint4 h = hi_img[(size_t)blk * img_pix + p0 + px], l = lo_img[(size_t)blk * img_pix + p0 + px];
+        unsigned* v = reinterpret_cast<unsigned*>(tile + px * pitch + blk * 8);
+        join2(h.x, l.x, v[0], v[1]); join2(h.y, l.y, v[2], v[3]); join2(h.z, l.z, v[4], v[5]); join2(h.w, l.w, v[6], v[7]);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < npx * nblk * 2; i += blockDim.x) {
+        const int px = i / (nblk * 2), q = i - px * (nblk * 2);
+        *reinterpret_cast<f32x4*>(src + (size_t)px * nblk * 8 + q * 4) = *reinterpret_cast<const f32x4*>(tile + px * pitch + q * 4);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <bool SPLIT>
+static hipError_t launch_split_join(float* f32, void* hi, void* lo, int n, int h, int w, int c, hipStream_t stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 != 0 || c > 512) return hipErrorInvalidValue;
+  const int img_pix = h * w, nblk = c / 8;
+  const long long groups = (long long)n * ((img_pix + 31) / 32);
+  const size_t lds = (size_t)32 * (nblk * 8 + 4) * sizeof(float);
+  const unsigned grid = (unsigned)(groups < 256 * 8 ? groups : 256 * 8);
+  hipLaunchKernelGGL(split_join_kernel<SPLIT>, dim3(grid), dim3(256), lds, stream, f32, reinterpret_cast<uint4*>(hi),
+                     reinterpret_cast<uint4*>(lo), img_pix, nblk, groups);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_f32(const float* in_nhwc, void* hi, void* lo, int n, int h, int w, int c, hipStream_t stream) {
+  return launch_split_join<true>(const_cast<float*>(in_nhwc), hi, lo, n, h, w, c, stream);
+}
+
+hipError_t launch_join_f32(const void* hi, const void* lo, float* out_nhwc, int n, int h, int w, int c, hipStream_t stream) {
+  return launch_split_join<false>(out_nhwc, const_cast<void*>(hi), const_cast<void*>(lo), n, h, w, c, stream);
+}
+
+}  // namespace dsen2

@@ -1,6 +1,6 @@
 // conv3x3_body32.hip — fp32 F->F 3x3 'same' convolution (F = 128 or 256): v_mfma_f32_32x32x2_f32 fed by LDS-DMA.
 //
-// The fp32 sibling of conv3x3_body16.hip (the DMA streams and their synchronisation rules: conv3x3_dma.h; the
+// The fp32 sibling of conv3x3_body16w.hip (the DMA streams and their synchronisation rules: conv3x3_dma.h; the
 // byte geometry is identical: a step is (tap, 32 channels) = 128 B per pixel and a 16 KiB weight chunk):
 //
 //   * weight chunks and input chunks go global -> LDS by `buffer_load_dwordx4 ... lds` issued from inline asm and
@@ -8,7 +8,7 @@
 //     (out-of-range lanes write the zero padding);
 //   * the input chunk lives in LDS as [channel group q: 8][pixel slot: 336][16 B]; a wave's 32-pixel block is rows
 //     (R, R + 8) x 16 columns of the tile — 8 halo rows = 144 slots = 0 mod 16 apart — so every ds_read_b128 of the
-//     loop is bank-conflict free (the adjacent-row 2x16 block of conv3x3_body.hip is 2-way);
+//     loop is bank-conflict free (an adjacent-row 2x16 block is 2-way);
 //   * the WEIGHTS are the MFMA's A operand: D[row = output channel][col = pixel].  A lane owns one pixel and, per
 //     accumulator, channels (r & 3) + 8*(r >> 2) + 4*(lane >> 5): register quad g = 16 contiguous bytes of NHWC,
 //     the two half-waves together 32 contiguous bytes per pixel.  The epilogue is 16-byte loads/stores with no
@@ -20,7 +20,8 @@
 //   * waves 4-7 issue their DMAs half a step after waves 0-3 (STG).
 //
 // Per wave: 64 channels x 64 pixels = 2 x 2 accumulators of 32x32; one step = 4 k-steps of 16 MFMAs and
-// 4 ds_read_b128.  Same arithmetic order per output element as conv3x3_body.hip: results are bit-identical.
+// 4 ds_read_b128.  Same arithmetic order per output element as the one-tile-per-workgroup kernel of conv3x3_mfma.hip:
+// results are bit-identical (tests/test_gpu_conv.py).
 #include <type_traits>
 
 #include "conv3x3_dma.h"
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body32_kernel(const ConvPa
   const int hsel = lane >> 5;
   const int rh = l31 >> 4, c16 = l31 & 15;
 
-  // persistent schedule (XCD-contiguous logical ids), as conv3x3_body.hip
+  // persistent schedule: logical ids remapped so that each XCD (blockIdx % 8) walks a contiguous run of items
   const int G = gridDim.x;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
@@ -187,7 +188,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body32_kernel(const ConvPa
         v = rr + v * p.res_scale;       // -ffp-contract=off: two roundings, as keras
       }
       if constexpr (!(ABL & 1))
-        // immediate soffset only: see the store-data hazard note in conv3x3_body.hip
+        // soffset must NOT be a register here: gfx950 reads the 128-bit store data late (the last quad of each
+        // 16-lane row last), and hipcc (ROCm 7.2) only pads the "store data overwritten too early" hazard when
+        // soffset is an immediate — with an SGPR soffset the next VALU write of v's first register corrupted lanes
+        // 12-15 / 28-31 on some schedules (experiments/README.md; tests/test_gpu_stress.py is the screen).
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, byte_off(g_, mb, pb, g), 0, 0);
       else
         asm volatile("" ::"v"(v));
@@ -372,17 +376,20 @@ static hipError_t launch_body32_feat(const ConvParams& p, int epilogue, int sub,
 // sub: 3 = deferred epilogue + wave-group stagger for both convolutions (default);
 //      2 = the same with conv-B not staggered; 0 = no deferral: conv-A staggered, conv-B with the whole residual
 //      tile prefetched under the last step; 1 = 0 without the stagger
-hipError_t launch_conv3x3_body32(const ConvParams& p, int feat, int epilogue, int sub, hipStream_t stream) {
+hipError_t launch_conv3x3_body32(const ConvParams& p, int feat, int epilogue, int sub, int ablate, hipStream_t stream) {
   if (!body32_supports(p, feat)) return hipErrorInvalidValue;
-  if (feat == 128 && g_body_ablate != 0) {
+#ifdef DSEN2_DIAG
+  if (feat == 128 && ablate != 0) {
 #define DSEN2_ABL(M)                                                                             \
-  if (g_body_ablate == M)                                                                        \
+  if (ablate == M)                                                                               \
     return epilogue == kEpiRelu ? launch_body32_one<128, 128, kEpiRelu, M>(p, stream)            \
                                 : launch_body32_one<128, 128, kEpiResidual, M, 2>(p, stream);
     DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31)
 #undef DSEN2_ABL
     return hipErrorInvalidValue;
   }
+#endif
+  if (ablate != 0) return hipErrorInvalidValue;     // timing-only ablations exist in the diagnostic build only
   if (feat == 128) return launch_body32_feat<128>(p, epilogue, sub, stream);
   if (feat == 256) return launch_body32_feat<256>(p, epilogue, sub, stream);
   return hipErrorInvalidValue;

@@ -1,4 +1,5 @@
-// conv3x3_dma.h — the LDS-DMA staging shared by conv3x3_body32.hip (fp32) and conv3x3_body16.hip (bf16).
+// conv3x3_dma.h — the LDS-DMA staging of conv3x3_body32.hip (fp32 body convolution; the bf16 kernel,
+// conv3x3_body16w.hip, carries its own wide-tile version of the same scheme).
 //
 // Byte geometry (identical for both: a step is (tap, 128 bytes of input channels per pixel)):
 //   input chunk  : [channel group q: 8][pixel slot: 336][16 B]  = 43,008 B, double buffered; slots 0..323 = the
@@ -10,7 +11,8 @@
 // offset is out of the descriptor's range writes zeros (= the convolution's zero padding), an EXEC-masked lane
 // writes nothing.  Issued from inline asm: through the builtin hipcc tracks the DMA in its waitcnt model and turns
 // every counted lgkmcnt(N) of the fragment pipeline into lgkmcnt(0).  hipcc therefore knows neither about these
-// vector-memory operations nor about the LDS they write, and the kernels spell the synchronisation out:
+// vector-memory operations nor about the LDS they write (M0 is saved and restored inside every asm statement), and
+// the kernels spell the synchronisation out:
 //   * vmcnt retires in ISSUE ORDER, all vector-memory operations of a wave together (loads, stores, DMAs);
 //   * weight chunk c is issued in step c-3 into ring slot c%4 (last read in step c-4, which ended with a barrier),
 //     retired by every wave's `s_waitcnt vmcnt(N)` at the END of step c-2 — N = a lower bound of what that wave
@@ -113,12 +115,15 @@ struct Stage {
     const unsigned m0v = lds_in + buf * IN_BYTES + (wave * QS + 64 * b) * 16;
     const unsigned so = cc * (KC * 4);
     const unsigned voff = LAZY_VOFF ? voff_of(b, st_y0, st_x0) : in_voff[LAZY_VOFF ? 0 : b];
+    // M0 is saved and restored inside the statement: hipcc reserves M0 and rejects it in a clobber list, so the
+    // compiler's own uses of M0 (none today) must never see the DMA's value
+    unsigned saved_m0;
     if (b < IN_BLOCKS - 1) {
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                   ::"s"(m0v), "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(saved_m0) : "s"(m0v), "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
     } else if (lane < 16) {          // slots 320-335 only: the next group's row starts at 336
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                   ::"s"(m0v), "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(saved_m0) : "s"(m0v), "v"(voff), "s"(in_rsrc), "s"(so) : "memory");
     }
   }
 
@@ -127,10 +132,13 @@ struct Stage {
   __device__ __forceinline__ void issue_w() {
     const unsigned so = (unsigned)(((wl_item % NS) * NCHUNK + wl_chunk) * (WCH * 4) + wave * 1024);
     const unsigned l0 = lds_w + st_slot * (WCH * 4) + wave * 1024;
+    unsigned saved_m0;
     asm volatile(
-        "s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %5 offen lds"
-        ::"s"(l0), "s"(l0 + 8192u), "v"(w_voff), "s"(w_rsrc), "s"(so), "s"(so + 8192u)
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen lds\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(saved_m0) : "s"(l0), "s"(l0 + 8192u), "v"(w_voff), "s"(w_rsrc), "s"(so), "s"(so + 8192u)
         : "memory");
     if (++wl_chunk == NCHUNK) {
       wl_chunk = 0;

@@ -267,31 +267,20 @@ static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-int g_out_variant = 1;    // 1 = 16x16x4 output-layer kernel (conv3x3_out.hip); 0 = padded 32-wide block of this file
-// tuning key 0 (dsen2_set_tuning): structure used for the F->F fp32 body convolutions packed from now on
-//   14 = DMA-fed kernel, deferred epilogue + wave-group stagger (conv3x3_body32.hip; 11-13 = its sub-variants 0-2);
-//   8 = register-staged persistent kernels: conv-A staggered (9), conv-B deferred (conv3x3_bodyd.hip; 10 = deferred both);
-//   4 = persistent kernel (conv3x3_body.hip); 0 = one tile per workgroup (the first correct version, kept as the
-//   independent implementation tools/stress_body_conv.py compares against)
-int g_body_variant = 14;
-
-bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g) {
+bool conv_pack_geometry(int cin, int cout, int epilogue, const Tuning& tune, PackGeom* g) {
   if (cin <= 0 || cout <= 0) return false;
   if (epilogue == kEpiSkipNCHW) {
     if (cout > 32 || (cin != 128 && cin != 256)) return false;
-    if (cout <= 16 && g_out_variant == 1) { *g = PackGeom{16, 16, cin, 16, 7}; return true; }   // conv3x3_out.hip
+    if (cout <= 16 && tune.out_variant == 1) { *g = PackGeom{16, 16, cin, 16, 7}; return true; }   // conv3x3_out.hip
     *g = PackGeom{32, 32, cin, 32, 0};
     return true;
   }
   if (cout != 128 && cout != 256) return false;
   if (cin <= 16) { *g = PackGeom{16, 128, 16, cout, 0}; return true; }
-  if (cin == 128 && cout == 128) {
-    const int v = g_body_variant;
-    *g = PackGeom{32, 128, cin, cout, v};   // every structure reads the same packing
-    return true;
-  }
-  if (cin == 256 && cout == 256) {   // no deferred form (8 chunks): persistent kernel, or the DMA-fed one (11-14)
-    *g = PackGeom{32, 128, cin, cout, g_body_variant >= 11 ? g_body_variant : g_body_variant >= 4 ? 4 : 0};
+  if (cin == cout) {
+    // every structure of the F->F body convolution reads the same packing (KC = 32, NT = 128):
+    // 11-14 = conv3x3_body32.hip sub-variants 0-3 (14 = default); 0 = one tile per workgroup (this file)
+    *g = PackGeom{32, 128, cin, cout, tune.body_variant >= 11 && tune.body_variant <= 14 ? tune.body_variant : 0};
     return true;
   }
   return false;
@@ -321,11 +310,6 @@ static inline uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
-// tuning key 4 (256->256 bf16 body convolution): 4 = 16x16x32 MFMA fed by LDS-DMA (conv3x3_body16.hip; 5-7 = its
-// A/B sub-variants); the 32x32x16 forms stay for A/B: 0 = one 8-wave workgroup per CU, 64-channel steps;
-// 1 = two 4-wave workgroups, 32-channel steps; 2 = conv-A with wave-group stagger + conv-B deferred; 3 = deferred both
-int g_bf16_variant = 4;
-
 void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch, bool perm16, uint16_t* dst) {
   // [slab][cc (chunk_ch channels)][tap][g (8 channels)][o (128)][j (8)]: one (slab, cc, tap) chunk is the LDS image
   const int ncc = cin / chunk_ch, nslab = cout / 128, ng = chunk_ch / 8;
@@ -342,25 +326,14 @@ void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch
             }
 }
 
-hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, hipStream_t stream) {
+hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, int ablate, hipStream_t stream) {
   const int cin_pad = geom.cin_pad, cout_pad = geom.cout_pad;
   if (geom.variant == 7 && epilogue == kEpiSkipNCHW) return launch_conv3x3_out(p, cin_pad, stream);
-  // 11-14: the DMA-fed kernel (conv3x3_body32.hip) and its sub-variants; tensors it cannot address fall through
-  if (geom.variant >= 11 && geom.variant <= 14 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW) {
-    if (body32_supports(p, cout_pad)) return launch_conv3x3_body32(p, cin_pad, epilogue, geom.variant - 11, stream);
-    return launch_conv3x3_body(p, cin_pad, epilogue, 4, stream);
-  }
-  // default (8): conv-B (residual) on the deferred-epilogue kernel; conv-A (ReLU) on the persistent kernel with the
-  // wave-group stagger (variant 9) — measured best of {4, 8, 9} for each epilogue (tools/ab_body_conv.py)
-  if (geom.variant == 8 && cin_pad == 128 && cout_pad == 128 && epilogue == kEpiResidual && g_body_ablate == 0 &&
-      bodyd_supports(p, 128))
-    return launch_conv3x3_bodyd(p, 128, epilogue, false, stream);
-  if (geom.variant == 8 && cin_pad == 128 && cout_pad == 128 && epilogue == kEpiRelu && g_body_ablate == 0)
-    return launch_conv3x3_body(p, cin_pad, epilogue, 9, stream);
-  if (geom.variant == 10 && cin_pad == 128 && cout_pad == 128 && epilogue != kEpiSkipNCHW && bodyd_supports(p, 128))
-    return launch_conv3x3_bodyd(p, 128, epilogue, false, stream);      // A/B: deferred kernel for both epilogues
-  if (geom.variant >= 4 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)
-    return launch_conv3x3_body(p, cin_pad, epilogue, (geom.variant == 8 || geom.variant == 10) ? 4 : geom.variant, stream);
+  // 11-14: the DMA-fed kernel (conv3x3_body32.hip) and its sub-variants.  An image it cannot address (>= 2 GiB of
+  // activations) is an error, not a silent switch of kernels: dsen2's entry points reject such shapes up front.
+  if (geom.variant >= 11 && geom.variant <= 14 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)
+    return launch_conv3x3_body32(p, cin_pad, epilogue, geom.variant - 11, ablate, stream);
+  if (ablate != 0) return hipErrorInvalidValue;
 #define DSEN2_CASE(CI, KC_, CO, NT_, EP) \
   if (cin_pad == CI && cout_pad == CO && epilogue == EP) return launch_one<CI, KC_, CO, NT_, EP>(p, stream);
   DSEN2_CASE(16, 16, 128, 128, kEpiRelu)

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(outk::THREADS, 2) void conv3x3_out_kernel(const Con
     s_off[r] = have ? hp * PSTR + qq * 4 : -1;
     g_off[r] = inb ? (gy * p.w + gx) * CIN + qq * 4 : -1;
   }
-  auto load_in = [&](int r, int cc) -> f32x4 {     // branch-free (see conv3x3_body.hip)
+  auto load_in = [&](int r, int cc) -> f32x4 {     // branch-free: a clamped address, zeros selected at the LDS store
     return *reinterpret_cast<const f32x4*>(in_img + (g_off[r] >= 0 ? g_off[r] : 0) + cc * KC);
   };
   auto store_in = [&](float* buf, int r, f32x4 t) {

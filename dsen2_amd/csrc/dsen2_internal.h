@@ -24,52 +24,54 @@ constexpr int kTile = 16;                 // output pixels per workgroup edge (1
 constexpr int kHalo = kTile + 2;          // 18
 constexpr int kHaloPix = kHalo * kHalo;   // 324
 
-enum Epilogue : int { kEpiRelu = 0, kEpiResidual = 1, kEpiSkipNCHW = 2 };
+enum Epilogue : int { kEpiRelu = 0, kEpiResidual = 1, kEpiSkipNCHW = 2, kEpiResidualF32 = 3 /* bf16 body kernel only */ };
 
 struct ConvParams {
-  const float* in;     // NHWC [n][h][w][CIN_PAD]
+  const float* in;     // NHWC [n][h][w][CIN_PAD]            (bf16 body kernel: bf16 NHWC)
   const float* wpk;    // packed weights (layout above)
   const float* bias;   // [COUT_PAD]
   const float* aux;    // kEpiResidual: NHWC [n][h][w][COUT]; kEpiSkipNCHW: NCHW [n][cout_real][h][w]
+                       // (bf16 body kernel, residual epilogues: the `hi` plane of the residual stream)
   float* out;          // NHWC [n][h][w][COUT] or NCHW [n][cout_real][h][w]  (bf16 body kernel, kEpiRelu: bf16 NHWC)
-  void* out2;          // bf16 body kernel, kEpiResidual: bf16 NHWC copy of `out`; otherwise unused
+  void* out2;          // bf16 body kernel, residual epilogues: the `lo` plane of the residual stream; otherwise unused
   int n, h, w;
   int tiles_x, tiles_y;
   int cout_real;       // kEpiSkipNCHW only
-  float res_scale;     // kEpiResidual only
-  int stagger;         // persistent body kernel: start-delay quantum (x 8128 cycles) per (workgroup mod 4); 0 = off
+  float res_scale;     // residual epilogues only
+};
+
+// Kernel-structure choices of a model.  The product library always uses the defaults; the diagnostic build
+// (-DDSEN2_DIAG, tools/ only) can change them through dsen2_diag_set for A/B measurements.
+struct Tuning {
+  int body_variant = 14;   // fp32 F->F body convolution: 11-14 = conv3x3_body32.hip sub-variants 0-3; 0 = one tile per
+                           // workgroup (conv3x3_mfma.hip, the independent first implementation)
+  int out_variant = 1;     // last layer: 1 = 16x16x4 kernel (conv3x3_out.hip); 0 = padded 32-wide block (conv3x3_mfma.hip)
+  int ablate = 0;          // timing-only ablation mask of the persistent body kernels (DSEN2_DIAG builds; wrong outputs)
 };
 
 // Supported (CIN_PAD, COUT_PAD, epilogue) combinations; returns hipErrorInvalidValue otherwise.
 struct PackGeom { int kc, nt, cin_pad, cout_pad, variant; };
-hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, hipStream_t stream);
-extern int g_body_variant;
-extern int g_out_variant;
+hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, int ablate, hipStream_t stream);
 // last layer, F -> Cout<=16, 16x16x4 MFMA (conv3x3_out.hip); weights packed with KC=16, NT=16
 hipError_t launch_conv3x3_out(const ConvParams& p, int feat, hipStream_t stream);
-extern int g_body_stagger;  // tuning key 3
-extern int g_body_ablate;   // timing-only ablation mask of the persistent body kernel (0 = off)
-// deferred-epilogue persistent kernel (conv3x3_bodyd.hip): fp32 F=128 and bf16 F=256 only, tensors < 4 GiB
-bool bodyd_supports(const ConvParams& p, int cout);
-hipError_t launch_conv3x3_bodyd(const ConvParams& p, int feat, int epilogue, bool bf16, hipStream_t stream);
 // DMA-fed fp32 kernel (conv3x3_body32.hip): F = 128 or 256, images < 2 GiB; weights packed with KC=32, NT=128
 bool body32_supports(const ConvParams& p, int cout);
-hipError_t launch_conv3x3_body32(const ConvParams& p, int feat, int epilogue, int sub, hipStream_t stream);
-// bf16-operand form of the persistent kernel: in bf16 NHWC, weights packed by pack_conv_weights_bf16_host
-hipError_t launch_conv3x3_body_bf16(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream);
-// kernel HWIO fp32 -> bf16 packed [slab][cc(64 ch)][tap][g(8 groups of 8 ch)][o(128)][8]; dst holds 9*cin*cout uint16
-// perm16: row o of a slab holds output channel 32*(o>>5) + 8*((o&15)>>2) + 4*((o>>4)&1) + (o&3) (conv3x3_body16.hip)
+hipError_t launch_conv3x3_body32(const ConvParams& p, int feat, int epilogue, int sub, int ablate, hipStream_t stream);
+// kernel HWIO fp32 -> bf16 packed [slab][cc (chunk_ch channels)][tap][g (groups of 8 ch)][o(128)][8]; dst holds
+// 9*cin*cout uint16.  perm16: row o of a slab holds output channel 32*(o>>5) + 8*((o&15)>>2) + 4*((o>>4)&1) + (o&3),
+// so that the two 16-row accumulators of a 32-channel pair give a lane 8 consecutive channels (conv3x3_body16w.hip)
 void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, int chunk_ch, bool perm16, uint16_t* dst);
-extern int g_bf16_variant;   // tuning key 4 (read when weights are packed and when the kernel is launched)
-inline int bf16_chunk_channels(int) { return 64; }   // every structure stages 64-channel chunks
-inline bool bf16_perm16(int variant) { return variant >= 4 && variant <= 7; }
-// 16x16x32-MFMA form fed by LDS-DMA (conv3x3_body16.hip), F = 256; weights packed with perm16
-hipError_t launch_conv3x3_body16(const ConvParams& p, int feat, int epilogue, int sub, hipStream_t stream);
-hipError_t launch_f32_to_bf16(const float* in, void* out_bf16, size_t count, hipStream_t stream);
-// persistent pipelined F->F kernel (conv3x3_body.hip); weights packed with KC=32, NT=128
-hipError_t launch_conv3x3_body(const ConvParams& p, int feat, int epilogue, int variant, hipStream_t stream);
+// bf16-operand body convolution, wide tile (conv3x3_body16w.hip), F = 128 or 256.  16-bit tensors are BLOCKED:
+// [n][C/8][h][w][8] (an 8-channel block = a plane of 16-byte pixels).  p.in bf16 blocked; weights packed by
+// pack_conv_weights_bf16_host(chunk_ch = 32, perm16).  kEpiRelu: p.out bf16 blocked.  kEpiResidual: the residual
+// stream as two blocked 16-bit tensors p.aux (hi = bf16 rounding, the next operand) / p.out2 (lo), updated in place.
+// kEpiResidualF32: same inputs, result to p.out as fp32 NHWC (last block).  `ablate` != 0 only in DSEN2_DIAG builds.
+hipError_t launch_conv3x3_body16w(const ConvParams& p, int feat, int epilogue, int ablate, hipStream_t stream);
+// fp32 NHWC tensor <-> blocked (hi, lo) tensors: hi = (u + 0x8000) >> 16, lo = u & 0xffff per value (c % 8 == 0)
+hipError_t launch_split_f32(const float* in_nhwc, void* hi, void* lo, int n, int h, int w, int c, hipStream_t stream);
+hipError_t launch_join_f32(const void* hi, const void* lo, float* out_nhwc, int n, int h, int w, int c, hipStream_t stream);
 // Geometry helpers for packing
-bool conv_pack_geometry(int cin, int cout, int epilogue, PackGeom* g);
+bool conv_pack_geometry(int cin, int cout, int epilogue, const Tuning& tune, PackGeom* g);
 size_t packed_weight_floats(const PackGeom& g);
 // host_kernel HWIO (3,3,cin,cout) -> packed layout (host memory, zero padded)
 void pack_conv_weights_host(const float* kernel_hwio, int cin, int cout, const PackGeom& g, float* dst);

@@ -46,26 +46,6 @@ hipError_t launch_pack_inputs(const float* x10, const float* x20, const float* x
   return hipGetLastError();
 }
 
-// ---- fp32 -> bf16 (round to nearest even) copy of an activation tensor ----------------------------
-// Used once per forward of a bf16 model: the first convolution runs in fp32 and its output is both the fp32
-// residual stream and, through this kernel, the bf16 operand of the first residual block.
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const f32x4* __restrict__ in, uint2* __restrict__ out, size_t n4) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const f32x4 v = in[i];
-    const unsigned short a = __builtin_bit_cast(unsigned short, (__bf16)v[0]), b = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
-    const unsigned short c = __builtin_bit_cast(unsigned short, (__bf16)v[2]), d = __builtin_bit_cast(unsigned short, (__bf16)v[3]);
-    out[i] = make_uint2((unsigned)a | ((unsigned)b << 16), (unsigned)c | ((unsigned)d << 16));
-  }
-}
-
-hipError_t launch_f32_to_bf16(const float* in, void* out_bf16, size_t count, hipStream_t stream) {
-  if (count % 4 != 0) return hipErrorInvalidValue;
-  const size_t n4 = count / 4;
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, stream,
-                     reinterpret_cast<const f32x4*>(in), reinterpret_cast<uint2*>(out_bf16), n4);
-  return hipGetLastError();
-}
-
 // ---- mirror-bilinear up-sampling (interp_patches, utils/patches.py:11-16) ----------------------
 // skimage.transform.resize(x/30000, (oh,ow), mode='reflect')*30000, order 1:
 //   src = scale*dst + offset with scale = in/out, offset = 0.5*scale - 0.5, evaluated in float32 with a

@@ -39,22 +39,16 @@ const char *dsen2_last_error(void);
 /* Number of visible HIP devices whose gcnArchName starts with "gfx950"; <0 on error. */
 int dsen2_device_count(void);
 
-/* Tuning knobs (no reference counterpart).  key 0 = structure of the fp32 F->F body convolution used by
- * models CREATED after the call (14 = default: DMA-fed kernel of conv3x3_body32.hip; 11-13 its sub-variants;
- * 0-10 = the register-staged kernels kept for A/B measurements; all variants give bit-identical results).  key 1 = timing-only
- * ablation mask of the persistent body kernel (diagnostics: outputs are wrong while it is non-zero).
- * key 2 = output-layer kernel, key 3 = start stagger quantum, key 4 = structure of the bf16 256->256 body
- * convolution (4 = default: 16x16x32 MFMA fed by LDS-DMA, conv3x3_body16.hip; 5-7 = its A/B
- * sub-variants; 0-3 = the 32x32x16 forms of conv3x3_body.hip / conv3x3_bodyd.hip), read when a model is CREATED.  Python: DSEN2_TUNING="key=value,..." applies them at load. */
-int dsen2_set_tuning(int key, int value);
-
 /* ---- network object -------------------------------------------------------------------------
  * dsen2_model_create  <->  s2model(input_shape, num_layers, feature_size)   utils/DSen2Net.py:18-43
  *   c10/c20/c60: channel counts of the 10 m / 20 m / 60 m inputs (c60 = 0 for the 2-input net).
  *   The output has the channel count of the last input and that input is added back (:35-41).
  *   feature_size must be a multiple of 128 (reference uses 128 and 256, testing/supres.py:56,59).
  *   precision: 0 = fp32 everywhere (exact-f32 MFMA); 1 = bf16 operands for the residual-block convolutions
- *   (v_mfma_f32_16x16x32_bf16 at F = 256, v_mfma_f32_32x32x16_bf16 at F = 128), fp32 accumulation, fp32 residual stream, fp32 first and last convolution.
+ *   (v_mfma_f32_16x16x32_bf16), fp32 accumulation, an exact fp32 residual stream (kept as two 16-bit planes, see
+ *   dsen2_split_f32), fp32 first and last convolution.
+ *   A model's kernel structures are fixed when it is created; the library has no process-global mutable state,
+ *   so any number of handles (one per rank / device) coexist.
  */
 int dsen2_model_create(dsen2_model **out, int c10, int c20, int c60, int num_layers, int feature_size,
                        int precision);
@@ -99,20 +93,42 @@ int dsen2_conv3x3_nhwc(const float *dev_in, const float *host_kernel, const floa
                        const float *dev_aux, float *dev_out, int n, int h, int w, int cin, int cout,
                        int epilogue, float res_scale, void *stream);
 
-/* bf16-operand form of one residual-block convolution (feat -> feat, feat = 128 or 256): dev_in_bf16 is NHWC
- * bf16; the fp32 HWIO kernel is rounded to bf16 (RNE) while packing; accumulation is fp32.
- *   epilogue 0: dev_out (bf16 NHWC)  = relu(conv + bias)
- *   epilogue 1: dev_out (fp32 NHWC)  = dev_aux (fp32 NHWC) + res_scale * (conv + bias), and dev_out2_bf16 = its
- *               bf16 copy (what the next block's first convolution reads)
+/* The same convolution on the one-tile-per-workgroup kernel (the library's first, register-staged structure):
+ * an independent implementation of the arithmetic for cross-checks of the persistent DMA-fed kernels
+ * (tests/test_gpu_conv.py, tools/stress_body_conv.py).  Bit-identical results are expected. */
+int dsen2_conv3x3_nhwc_ref(const float *dev_in, const float *host_kernel, const float *host_bias,
+                           const float *dev_aux, float *dev_out, int n, int h, int w, int cin, int cout,
+                           int epilogue, float res_scale, void *stream);
+
+/* 16-bit tensors of a precision-1 model are BLOCKED: [n][C/8][h][w][8] — an 8-channel block is a plane of
+ * 16-byte pixels (the layout in which the bf16 kernel's loads, stores and LDS-DMA reads are contiguous runs).
+ *
+ * The residual stream of such a model: each fp32 value u (its bit pattern) is held in two blocked 16-bit tensors,
+ *   hi = (u + 0x8000) >> 16   the bf16 rounding of u (ties away from zero) = the next convolution's operand
+ *   lo = u & 0xffff
+ * and u = ((hi - (lo >> 15)) << 16) | lo restores it bit for bit (all arithmetic mod 2^16 / 2^32; every bit
+ * pattern, NaNs included, round-trips).  dsen2_split_f32: fp32 NHWC [n,h,w,c] -> blocked hi, lo (n*h*w*c uint16
+ * each); dsen2_join_f32 is the inverse.  c % 8 == 0, c <= 512. */
+int dsen2_split_f32(const float *dev_in_nhwc, void *dev_hi, void *dev_lo, int n, int h, int w, int c, void *stream);
+int dsen2_join_f32(const void *dev_hi, const void *dev_lo, float *dev_out_nhwc, int n, int h, int w, int c, void *stream);
+
+/* bf16-operand form of one residual-block convolution (feat -> feat, feat = 128 or 256): dev_in_bf16 is a BLOCKED
+ * bf16 tensor; the fp32 HWIO kernel is rounded to bf16 (RNE) while packing; accumulation is fp32, starting from the bias.
+ *   epilogue 0: dev_out (bf16 blocked, RNE) = relu(conv + bias)                           DSen2Net.py:10-11
+ *   epilogue 1: (dev_res_hi, dev_res_lo) = split(join(hi, lo) + res_scale * (conv + bias)), in place; dev_out unused
+ *   epilogue 3: dev_out (fp32 NHWC) = join(hi, lo) + res_scale * (conv + bias)            DSen2Net.py:12-15
  * Test path (packs on every call, synchronises). */
 int dsen2_conv3x3_body_bf16(const void *dev_in_bf16, const float *host_kernel, const float *host_bias,
-                            const float *dev_aux, void *dev_out, void *dev_out2_bf16, int n, int h, int w, int feat,
+                            void *dev_res_hi, void *dev_res_lo, void *dev_out, int n, int h, int w, int feat,
                             int epilogue, float res_scale, void *stream);
 
 /* Body-convolution micro-benchmark hook: runs `iters` launches of the 128->128 (or F->F) kernel on
  * caller-provided NHWC buffers with already-packed weights held by `m` (layer index `layer`, 1-based
  * body conv number) and reports the mean kernel time in milliseconds measured with HIP events on
- * `stream`.  Used by bench.py for the roofline figure. */
+ * `stream`.  Used by bench.py for the roofline figure.
+ * precision-1 models: dev_in is bf16 blocked; odd layers write bf16 blocked to dev_out; even (residual) layers take
+ * dev_aux = one fp32-sized buffer holding the blocked hi tensor followed by the lo tensor and update it in place
+ * (the last block's residual layer writes fp32 NHWC to dev_out instead). */
 int dsen2_model_time_body_conv(dsen2_model *m, int layer, const float *dev_in, const float *dev_aux,
                                float *dev_out, int n, int h, int w, int iters, void *stream,
                                float *ms_per_launch);

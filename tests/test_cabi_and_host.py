@@ -26,6 +26,21 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert b'gfx950' in lib.dsen2_version()
 
 
+def test_product_abi_has_no_tuning_or_diagnostic_switches():
+    """no global mutable state.  Kernel-structure switches and timing-only ablations exist only in the
+    diagnostic build (python -m dsen2_amd.build --diag), never in the product library or its header."""
+    from dsen2_amd import _lib
+    lib = _lib.load()
+    for name in ('dsen2_set_tuning', 'dsen2_diag_set'):
+        assert not hasattr(lib, name), name
+    header = open(os.path.join(ROOT, 'include', 'dsen2_hip.h')).read()
+    assert 'set_tuning' not in header and 'diag_set' not in header
+    with pytest.raises(_lib.DSen2Error):
+        _lib.diag_set(0, 0)
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    assert b'DIAGNOSTIC build' not in blob
+
+
 def test_code_object_targets_gfx950_only():
     from dsen2_amd import _lib
     blob = open(_lib.LIB_PATH, 'rb').read()

@@ -104,6 +104,22 @@ def test_delta_kernel_shifts_exactly():
         assert not other.any()
 
 
+@pytest.mark.parametrize('feat,n,h,w', [(128, 3, 21, 37), (128, 40, 32, 32), (256, 2, 32, 32), (256, 1, 19, 16)])
+def test_persistent_kernel_is_bit_identical_to_the_reference_structure(feat, n, h, w):
+    """The persistent DMA-fed body kernel (conv3x3_body32.hip) and the one-tile-per-workgroup kernel
+    (dsen2_conv3x3_nhwc_ref) compute the same sums in the same order: bit-identical, both epilogues."""
+    rng = np.random.default_rng(feat + n)
+    x = _nhwc(_rand(rng, (n, feat, h, w)))
+    res = _nhwc(_rand(rng, (n, feat, h, w)))
+    k = _rand(rng, (3, 3, feat, feat), np.sqrt(2.0 / (9 * feat)))
+    b = _rand(rng, (feat,), 0.1)
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    for epi, aux in ((0, None), (1, res)):
+        a = conv3x3_nhwc(x, k, b, epilogue=epi, aux=aux)
+        r = conv3x3_nhwc(x, k, b, epilogue=epi, aux=aux, ref=True)
+        assert torch.equal(a, r), (feat, epi)
+
+
 def test_bad_arguments_raise():
     from dsen2_amd import _lib
     from dsen2_amd.DSen2Net import conv3x3_nhwc

@@ -118,25 +118,6 @@ def test_single_pixel_and_tiny_images():
         assert do.rmse(y, ref) < 5e-6, (h, w)
 
 
-def test_every_fp32_body_structure_gives_the_same_bits():
-    """dsen2_set_tuning(0, v): the register-staged kernels kept for A/B and the sub-variants of the DMA-fed kernel
-    all compute the same sums in the same order, so whole-network outputs must be bit-identical (ragged image)."""
-    from dsen2_amd import _lib
-    default = 14
-    flat = do.he_uniform_weights(10, 6, 3, 128, seed=5, bias_scale=0.05)
-    xs = do.synthetic_inputs(3, 21, 37, (4, 6), seed=5)
-    outs = {}
-    try:
-        for v in (0, 4, 8, 9, 10, 11, 12, 13, 14):
-            _lib.call('dsen2_set_tuning', 0, v)
-            outs[v] = _model((4, 6), 3, 128, flat).predict(xs)
-    finally:
-        _lib.call('dsen2_set_tuning', 0, default)
-    for v, y in outs.items():
-        assert np.array_equal(y, outs[default]), 'variant %d differs' % v
-    assert do.rmse(outs[default], c_oracle.forward(xs, flat, 3, 128)) < 5e-6
-
-
 def test_forward_timed_runs_the_same_forward():
     """dsen2_model_forward_timed (bench.py's roofline hook): same output as dsen2_model_forward, a plausible time."""
     flat = do.he_uniform_weights(10, 6, 2, 128, seed=6, bias_scale=0.05)

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""A/B the body-convolution variants in ONE process, interleaved rounds (guide §5.4 rule 24).
+"""A/B the fp32 body-convolution structures in ONE process, interleaved rounds (guide §5.4 rule 24).
+Needs the DIAGNOSTIC library (the product library has no structure switch):
 
-    python tools/ab_body_conv.py [--variants 0,1,2,3] [--rounds 5] [--batch 512]
+    python -m dsen2_amd.build --diag
+    DSEN2_HIP_LIB=build/libdsen2_hip_diag.so python tools/ab_body_conv.py [--variants 0,11,12,13,14] [--rounds 5] [--batch 512]
+
+14 = default (conv3x3_body32.hip: deferred epilogue + wave-group stagger), 11-13 its sub-variants, 0 = one tile per
+workgroup (conv3x3_mfma.hip).
 """
 import argparse
 import json
@@ -16,7 +21,7 @@ from dsen2_amd import _lib, weights as W          # noqa: E402
 from dsen2_amd.DSen2Net import s2model            # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--variants', default='8,14')
+ap.add_argument('--variants', default='0,14')
 ap.add_argument('--rounds', type=int, default=5)
 ap.add_argument('--batch', type=int, default=512)
 ap.add_argument('--hw', type=int, default=32)
@@ -27,11 +32,11 @@ variants = [int(v) for v in args.variants.split(',')]
 flat = W.random_he_uniform(10, 6, 6, 128, seed=1, bias_scale=0.05)
 models = {}
 for v in variants:
-    _lib.call('dsen2_set_tuning', 0, v)
+    _lib.diag_set(0, v)
     m = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128)
     m.set_weights_flat(flat)
     models[v] = m
-_lib.call('dsen2_set_tuning', 0, 14)
+_lib.diag_set(0, 14)
 
 B, H = args.batch, args.hw
 a = torch.randn((B, H, H, 128), device='cuda')
