@@ -46,6 +46,7 @@ constexpr int kBf16ChunkChannels = 32;   // input channels per weight chunk of c
 // Diagnostic build only (tools/): defaults copied into models and single-layer calls made AFTER dsen2_diag_set.
 // The product library has no mutable globals — a model's kernel structures are fixed constants.
 Tuning g_diag_tuning;
+unsigned long long* g_diag_stamps = nullptr;   // device buffer for ablation bit 32 (dsen2_diag_set_stamps)
 #endif
 Tuning default_tuning() {
 #ifdef DSEN2_DIAG
@@ -101,7 +102,16 @@ int dsen2_diag_set(int key, int value) {
     g_diag_tuning.out_variant = value;
     return DSEN2_OK;
   }
+  if (key == 3) {   // at most `value` workgroups for the bf16 body kernel (0 = one per CU): per-CU vs chip-wide limits
+    g_diag_tuning.grid_cap = value;
+    return DSEN2_OK;
+  }
   return fail(DSEN2_ERR_INVALID, "unknown diagnostic key %d", key);
+}
+// device buffer (>= 64 KiB) the stamping build of the bf16 body kernel (ablation mask 32) writes s_memtime values to
+int dsen2_diag_set_stamps(void* dev_buffer) {
+  g_diag_stamps = reinterpret_cast<unsigned long long*>(dev_buffer);
+  return DSEN2_OK;
 }
 #endif
 
@@ -223,7 +233,7 @@ static ConvParams make_params(const float* in, const float* wpk, const float* bi
   p.in = in; p.wpk = wpk; p.bias = bias; p.aux = aux; p.out = out; p.out2 = nullptr;
   p.n = n; p.h = h; p.w = w;
   p.tiles_x = (w + kTile - 1) / kTile; p.tiles_y = (h + kTile - 1) / kTile;
-  p.cout_real = cout_real; p.res_scale = scale;
+  p.cout_real = cout_real; p.res_scale = scale; p.diag = nullptr;
   return p;
 }
 
@@ -437,8 +447,11 @@ int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, c
     epi = last ? kEpiResidualF32 : kEpiResidual;
   }
   const int abl = m->tune.ablate;
+#ifdef DSEN2_DIAG
+  p.diag = g_diag_stamps;
+#endif
   auto launch = [&]() -> hipError_t {
-    return L.bf16 ? launch_conv3x3_body16w(p, m->feat, epi, abl, stream) : launch_conv3x3(p, L.geom, L.epilogue, abl, stream);
+    return L.bf16 ? launch_conv3x3_body16w(p, m->feat, epi, abl, stream, m->tune.grid_cap) : launch_conv3x3(p, L.geom, L.epilogue, abl, stream);
   };
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));

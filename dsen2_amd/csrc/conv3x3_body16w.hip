@@ -117,7 +117,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 //      kEpiResidual   (aux, out2) = split(join(aux, out2) + res_scale * (conv + bias))      conv-B, in place on the planes
 //      kEpiResidualF32  out (fp32 NHWC) = join(aux, out2) + res_scale * (conv + bias)       conv-B of the last block
 // CINW = 32-bit words per input pixel (= F / 2).  ABL (diagnostic builds): timing-only ablation mask
-// (1 no stores, 2 no residual loads, 4 no weight stream, 8 no input stream, 16 no barriers).
+// (1 no stores, 2 no residual loads, 4 no weight stream, 8 no input stream, 16 no barriers; 32 = full kernel + time stamps).
 template <int CINW, int COUT, int EPI, int ABL>
 __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvParams p, const int n_items) {
   constexpr int NCC = CINW / 16;              // 32-channel chunks
@@ -244,6 +244,15 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
 
   f32x4 acc[MB][PB];
 
+  // diagnostic builds, ablation bit 32: s_memtime stamps of waves 0 and 7 of the first four workgroups, 32 per item
+  int stamp_it = 0;
+  auto stamp = [&](int k) {
+    if constexpr ((ABL & 32) != 0) {
+      if (p.diag && lid < 4 && (wave == 0 || wave == 7) && lane == 0)
+        p.diag[(((size_t)lid * 2 + (wave == 7)) * 16 + (stamp_it & 15)) * 32 + k] = __builtin_amdgcn_s_memtime();
+    }
+  };
+
   // ---- epilogue of one item: lane = pixel (row 4*wp + (pb>>1), column 16*(pb&1) + l15), group (pr, pb) =
   // 8 consecutive channels slab*128 + wn*64 + 32*pr + 8*q4 held by accumulators 2*pr and 2*pr+1 ----
   auto epilogue = [&](int item, bool valid) {
@@ -361,12 +370,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
       };
       load_pass(0);
       load_pass(1);
+      stamp(14);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         __builtin_amdgcn_sched_barrier(0);
         if (j + 2 < 4) load_pass(j + 2);
         __builtin_amdgcn_sched_barrier(0);
         finish_pass(j);
+        stamp(15 + j);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -381,8 +392,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
     for (int pb = 0; pb < PB; ++pb) acc[mb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int it = 0; it <= my_items; ++it) {
+    stamp_it = it;
+    stamp(0);
     epilogue(it > 0 ? lid + (it - 1) * G : lid, it > 0);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(1);
     if (it == my_items) break;
     const int item = lid + it * G;
     const bool have_next_item = it + 1 < my_items;
@@ -403,6 +417,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
       for (int mb = 0; mb < MB; ++mb) w_cur[mb] = read_w1(mb, wb);
       read_x(x_cur, in_s, 0);
     }
+    stamp(2);
 
     // ONE copy of the nine-step body for every input chunk (a separate copy for the item's first chunk makes the
     // register allocator permute all 32 accumulators between the two copies and spill); the first chunk's five
@@ -466,6 +481,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
           wait_vmcnt<kN>();
         }
         if constexpr (!(ABL & 16)) __syncthreads();
+        if constexpr ((ABL & 32) != 0) {
+          if (cc == 0) stamp(3 + tap);
+          if (tap == 8 && cc == 1) stamp(12);
+          if (tap == 8 && cc == NCC - 1) stamp(13);
+        }
       };
       step(std::integral_constant<int, 0>{});
       step(std::integral_constant<int, 1>{});
@@ -484,7 +504,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
 }
 
 template <int CINW, int COUT, int EPI, int ABL = 0>
-static hipError_t launch_body16w_one(ConvParams p, hipStream_t stream) {
+static hipError_t launch_body16w_one(ConvParams p, hipStream_t stream, int grid_cap) {
   auto kern = conv3x3_body16w_kernel<CINW, COUT, EPI, ABL>;
   static bool attr_set[64] = {};
   static int cus[64] = {};
@@ -505,33 +525,34 @@ static hipError_t launch_body16w_one(ConvParams p, hipStream_t stream) {
   p.tiles_y = (p.h + TH - 1) / TH;
   const long long items = (long long)p.n * p.tiles_x * p.tiles_y * (COUT / 128);
   if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;
-  const int grid = (int)(items < cus[dev] ? items : cus[dev]);
+  int grid = (int)(items < cus[dev] ? items : cus[dev]);
+  if (grid_cap > 0 && grid_cap < grid) grid = grid_cap;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, stream, p, (int)items);
   return hipGetLastError();
 }
 
 template <int F>
-static hipError_t launch_body16w_feat(const ConvParams& p, int epilogue, int ablate, hipStream_t stream) {
+static hipError_t launch_body16w_feat(const ConvParams& p, int epilogue, int ablate, hipStream_t stream, int grid_cap) {
 #ifdef DSEN2_DIAG
 #define DSEN2_ABL(M)                                                                                         \
   if (ablate == M)                                                                                           \
-    return epilogue == kEpiRelu       ? launch_body16w_one<F / 2, F, kEpiRelu, M>(p, stream)                  \
-           : epilogue == kEpiResidual ? launch_body16w_one<F / 2, F, kEpiResidual, M>(p, stream)              \
-                                      : launch_body16w_one<F / 2, F, kEpiResidualF32, M>(p, stream);
-  DSEN2_ABL(1) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31)
+    return epilogue == kEpiRelu       ? launch_body16w_one<F / 2, F, kEpiRelu, M>(p, stream, grid_cap)                  \
+           : epilogue == kEpiResidual ? launch_body16w_one<F / 2, F, kEpiResidual, M>(p, stream, grid_cap)              \
+                                      : launch_body16w_one<F / 2, F, kEpiResidualF32, M>(p, stream, grid_cap);
+  DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31) DSEN2_ABL(32)
 #undef DSEN2_ABL
 #endif
   if (ablate != 0) return hipErrorInvalidValue;
-  if (epilogue == kEpiRelu) return launch_body16w_one<F / 2, F, kEpiRelu>(p, stream);
-  if (epilogue == kEpiResidual) return launch_body16w_one<F / 2, F, kEpiResidual>(p, stream);
-  if (epilogue == kEpiResidualF32) return launch_body16w_one<F / 2, F, kEpiResidualF32>(p, stream);
+  if (epilogue == kEpiRelu) return launch_body16w_one<F / 2, F, kEpiRelu>(p, stream, grid_cap);
+  if (epilogue == kEpiResidual) return launch_body16w_one<F / 2, F, kEpiResidual>(p, stream, grid_cap);
+  if (epilogue == kEpiResidualF32) return launch_body16w_one<F / 2, F, kEpiResidualF32>(p, stream, grid_cap);
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_conv3x3_body16w(const ConvParams& p, int feat, int epilogue, int ablate, hipStream_t stream) {
+hipError_t launch_conv3x3_body16w(const ConvParams& p, int feat, int epilogue, int ablate, hipStream_t stream, int grid_cap) {
   if (epilogue != kEpiRelu && (!p.aux || !p.out2)) return hipErrorInvalidValue;
-  if (feat == 128) return launch_body16w_feat<128>(p, epilogue, ablate, stream);
-  if (feat == 256) return launch_body16w_feat<256>(p, epilogue, ablate, stream);
+  if (feat == 128) return launch_body16w_feat<128>(p, epilogue, ablate, stream, grid_cap);
+  if (feat == 256) return launch_body16w_feat<256>(p, epilogue, ablate, stream, grid_cap);
   return hipErrorInvalidValue;
 }
 

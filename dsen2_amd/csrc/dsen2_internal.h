@@ -38,6 +38,7 @@ struct ConvParams {
   int tiles_x, tiles_y;
   int cout_real;       // kEpiSkipNCHW only
   float res_scale;     // residual epilogues only
+  unsigned long long* diag;   // DSEN2_DIAG builds, ablation bit 32: in-kernel time stamps (tools/stamp_body_conv.py); else NULL
 };
 
 // Kernel-structure choices of a model.  The product library always uses the defaults; the diagnostic build
@@ -47,6 +48,7 @@ struct Tuning {
                            // workgroup (conv3x3_mfma.hip, the independent first implementation)
   int out_variant = 1;     // last layer: 1 = 16x16x4 kernel (conv3x3_out.hip); 0 = padded 32-wide block (conv3x3_mfma.hip)
   int ablate = 0;          // timing-only ablation mask of the persistent body kernels (DSEN2_DIAG builds; wrong outputs)
+  int grid_cap = 0;        // DSEN2_DIAG builds: launch at most this many workgroups of the bf16 body kernel (0 = one per CU)
 };
 
 // Supported (CIN_PAD, COUT_PAD, epilogue) combinations; returns hipErrorInvalidValue otherwise.
@@ -66,7 +68,7 @@ void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, in
 // pack_conv_weights_bf16_host(chunk_ch = 32, perm16).  kEpiRelu: p.out bf16 blocked.  kEpiResidual: the residual
 // stream as two blocked 16-bit tensors p.aux (hi = bf16 rounding, the next operand) / p.out2 (lo), updated in place.
 // kEpiResidualF32: same inputs, result to p.out as fp32 NHWC (last block).  `ablate` != 0 only in DSEN2_DIAG builds.
-hipError_t launch_conv3x3_body16w(const ConvParams& p, int feat, int epilogue, int ablate, hipStream_t stream);
+hipError_t launch_conv3x3_body16w(const ConvParams& p, int feat, int epilogue, int ablate, hipStream_t stream, int grid_cap = 0);
 // fp32 NHWC tensor <-> blocked (hi, lo) tensors: hi = (u + 0x8000) >> 16, lo = u & 0xffff per value (c % 8 == 0)
 hipError_t launch_split_f32(const float* in_nhwc, void* hi, void* lo, int n, int h, int w, int c, hipStream_t stream);
 hipError_t launch_join_f32(const void* hi, const void* lo, float* out_nhwc, int n, int h, int w, int c, hipStream_t stream);

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of the bf16 body convolution (diagnostic build, ablation mask 32): s_memtime stamps of waves 0
+and 7 of the first four workgroups around the epilogue and the first steps of every item.
+
+    python -m dsen2_amd.build --diag
+    DSEN2_HIP_LIB=build/libdsen2_hip_diag.so python tools/stamp_body_conv.py [layer]     (layer 1 = conv-A, 2 = conv-B)
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dsen2_amd import _lib, weights as W          # noqa: E402
+from dsen2_amd.DSen2Net import s2model            # noqa: E402
+
+layer = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+F, B, H, D = 256, 256, 32, 3
+lib = _lib.load()
+buf = torch.zeros(4 * 2 * 16 * 32, dtype=torch.int64, device='cuda')
+lib.dsen2_diag_set_stamps.argtypes = [ctypes.c_void_p]
+lib.dsen2_diag_set_stamps(ctypes.c_void_p(buf.data_ptr()))
+_lib.diag_set(1, 32)
+m = s2model(((4, None, None), (6, None, None)), num_layers=D, feature_size=F, precision='bf16')
+m.set_weights_flat(W.random_he_uniform(10, 6, D, F, seed=1))
+_lib.diag_set(1, 0)
+a = torch.randn((B, H, H, F), device='cuda').to(torch.bfloat16); r = torch.randn((B, H, H, F), device='cuda'); o = torch.empty_like(r)
+for _ in range(3):
+    ms = m.time_body_conv(layer, a, r if layer == 2 else None, o, iters=5)
+torch.cuda.synchronize()
+st = buf.cpu().numpy().reshape(4, 2, 16, 32)
+print('layer %d: %.4f ms per launch (stamping build)' % (layer, ms))
+names = {0: 'loop top', 14: 'residual loads issued', 15: 'pass 0 done', 16: 'pass 1 done', 17: 'pass 2 done', 18: 'pass 3 done',
+         1: 'epilogue done', 2: 'first fragments', 3: 'step 0', 4: 'step 1', 5: 'step 2', 6: 'step 3', 7: 'step 4', 8: 'step 5',
+         9: 'step 6', 10: 'step 7', 11: 'step 8', 12: 'end of chunk 1', 13: 'end of item'}
+order = [0, 14, 15, 16, 17, 18, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13]
+for wg in (0, 1):
+    for wv in (0, 1):
+        print('workgroup %d wave %d: cycles since the item loop top of item 0 (100 MHz s_memtime ticks x clock ratio)' % (wg, 7 * wv))
+        t0 = st[wg, wv, 0, 0]
+        for it in range(5):
+            row = st[wg, wv, it]
+            if row[0] == 0:
+                continue
+            prev = row[0]
+            parts = []
+            for k in order:
+                if row[k] == 0:
+                    continue
+                parts.append('%s +%d' % (names[k], row[k] - prev))
+                prev = row[k]
+            print('  item %d @%d: %s' % (it, row[0] - t0, '; '.join(parts)))
