@@ -13,7 +13,8 @@ the two translation units to ISA with exactly the product's flags and fails (Asm
   * every kernel ends with `s_waitcnt vmcnt(0)` before `s_endpgm` (no DMA may still be writing LDS that already
     belongs to the next workgroup);
   * the bf16 kernel's epilogues contain exactly the number of vector-memory operations its first-chunk waits count
-    as younger than their target (conv3x3_body16w.hip, E_OPS): an over-count there would be a weaker wait.
+    as younger than their target (conv3x3_body16w.hip, E_OPS): an over-count there would be a weaker wait;
+  * nothing is called out of line (an epilogue that is not inlined passes 128 accumulators through memory).
 
 dsen2_amd.build runs it on every product build; tests/test_dma_asm_contract.py runs it in the CPU suite.
 """
@@ -82,6 +83,7 @@ def check_listing(text, src):
     saves = sum(1 for ln in code if re.match(r's_mov_b32 s\d+, m0', ln))
     need(saves > 0, 'the DMA statements no longer save M0')
     need(not any('scratch_' in ln for ln in code), 'a DMA kernel spills registers')
+    need(not any(ln.startswith(('s_swappc', 's_call')) for ln in code), 'a DMA kernel calls a function (an epilogue was not inlined)')
     kernels = _kernels(text)
     need(kernels, 'no kernel found')
     n_dma_kernels = 0
@@ -94,9 +96,10 @@ def check_listing(text, src):
              'kernel %s does not drain its DMAs before s_endpgm' % name, back[-3:])
     need(n_dma_kernels > 0, 'no LDS-DMA kernel found')
     if src == 'conv3x3_body16w.hip':
-        # E_OPS of the kernel: epilogue 0 = 16 stores; 1 and 3 = 32 loads + 32 stores; (compiler-visible buffer
-        # operations only: the DMAs are `... lds`)
-        expect = {0: (0, 16), 1: (32, 32), 3: (32, 32)}
+        # E_OPS of the kernel: epilogue 0 = 16 stores; 1 and 3 = 32 loads + 32 stores (compiler-visible buffer
+        # operations only: the DMAs are `... lds`), once in each of the two copies of the item loop (issuing waves
+        # 0-3 / worker waves 4-7)
+        expect = {0: (0, 32), 1: (64, 64), 3: (64, 64)}
         found = 0
         for name, body in _kernels(text).items():
             m = re.search(r'conv3x3_body16w_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)

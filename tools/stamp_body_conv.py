@@ -34,8 +34,10 @@ st = buf.cpu().numpy().reshape(4, 2, 16, 32)
 print('layer %d: %.4f ms per launch (stamping build)' % (layer, ms))
 names = {0: 'loop top', 14: 'residual loads issued', 15: 'pass 0 done', 16: 'pass 1 done', 17: 'pass 2 done', 18: 'pass 3 done',
          1: 'epilogue done', 2: 'first fragments', 3: 'step 0', 4: 'step 1', 5: 'step 2', 6: 'step 3', 7: 'step 4', 8: 'step 5',
-         9: 'step 6', 10: 'step 7', 11: 'step 8', 12: 'end of chunk 1', 13: 'end of item'}
-order = [0, 14, 15, 16, 17, 18, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13]
+         9: 'step 6', 10: 'step 7', 11: 'step 8', 12: 'end of chunk 1', 13: 'end of item',
+         31: 'chunk 2 tap 0 end', 19: 'tap1 DMAs issued', 20: 'tap1 MFMAs issued', 21: 'tap1 own DMA wait', 22: 'tap1 barrier',
+         30: 'tap 2 end', 23: 'tap3 DMAs issued', 24: 'tap3 MFMAs issued', 25: 'tap3 own DMA wait', 26: 'tap3 barrier'}
+order = [0, 14, 15, 16, 17, 18, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 31, 19, 20, 21, 22, 30, 23, 24, 25, 26, 13]
 for wg in (0, 1):
     for wv in (0, 1):
         print('workgroup %d wave %d: cycles since the item loop top of item 0 (100 MHz s_memtime ticks x clock ratio)' % (wg, 7 * wv))
