@@ -120,7 +120,10 @@ hipError_t launch_upsample(const float* in, float* out, int planes, int h, int w
 __device__ __forceinline__ int symmetric_index(int q, int n) {   // q = index in the image frame, may be <0 or >=n
   if (q < 0) q = -1 - q;
   if (q >= n) q = 2 * n - 1 - q;
-  return q;
+  // One reflection covers every origin the tiling arithmetic produces (|pad| <= border <= n).  An origin that does
+  // not belong to this image (inconsistent image sizes handed in by a caller; the Python layer raises ValueError
+  // first) must still never read outside it: clamp.
+  return q < 0 ? 0 : (q >= n ? n - 1 : q);
 }
 
 // One thread per output PIXEL: it reads the pixel's C interleaved source values once (contiguous 4*C bytes) and

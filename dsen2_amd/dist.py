@@ -4,8 +4,8 @@ The forward pass has no exchange step (patches are independent), so
 collectives and neither is on the per-layer path:
   C1  broadcast_weights : rank 0 reads the checkpoint once, everyone receives the flat float32 vector
                           (7.16 MB DSen2, 151 MB VDSen2) with one broadcast
-  C2  gather_patches    : each rank's predictions are collected with one all-gather into a
-                          pre-sized buffer (the "gather of outputs over xGMI")
+  C2  gather_to_root    : each rank's (inner-cropped) predictions go to rank 0 with ONE gather into views of one
+                          pre-sized buffer (the "gather of outputs over xGMI"); no other rank receives anything
 Partitioning: contiguous ranges of the row-major patch index, ceil(N/R) per rank (last ranks may be
 short or empty).  With backend "nccl" (= RCCL on ROCm) tensors stay on the GPU; with "gloo" (CPU tests)
 they are staged through host memory.
@@ -39,19 +39,25 @@ def _collective_device(t):
     return t.device if backend == 'nccl' else torch.device('cpu')
 
 
-def gather_patches(local, total):
-    """All ranks contribute their [count, ...] slice (shard_range order); all ranks get [total, ...]."""
+def gather_to_root(send, total, dst=0):
+    """C2.  Every rank passes `send` = a [per_rank(total, world), ...] tensor whose first shard_range(total)[1]
+    rows are its results (the rest is padding that is never read: allocate the buffer at that size and fill it in
+    place, no copy is made here).  Rank `dst` returns a [total, ...] tensor (a view of the one receive buffer, in
+    patch order); every other rank returns None and allocates nothing."""
     rank, world = rank_world()
     if world == 1:
-        assert local.shape[0] == total
-        return local
+        return send[:total]
     per = per_rank(total, world)
-    cdev = _collective_device(local)
-    padded = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
-    padded[:local.shape[0]] = local.to(cdev)
-    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
-    td.all_gather_into_tensor(out, padded)
-    return out[:total].to(local.device)
+    assert send.shape[0] == per, (send.shape, per)
+    cdev = _collective_device(send)
+    src = send if send.device == cdev else send.to(cdev)
+    if rank == dst:
+        recv = torch.empty((world * per,) + tuple(send.shape[1:]), dtype=send.dtype, device=cdev)
+        td.gather(src, list(recv.chunk(world)), dst=dst)
+        out = recv[:total]
+        return out if out.device == send.device else out.to(send.device)
+    td.gather(src, None, dst=dst)
+    return None
 
 
 def broadcast_weights(flat, count, device=None, src=0):

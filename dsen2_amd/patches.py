@@ -131,8 +131,16 @@ def device_origins(origins_lr, scale, device):
     return torch.from_numpy(np.ascontiguousarray(origins_lr * scale, dtype=np.int32)).to(device)
 
 
+def _check_ratio(hi, lo, scale):
+    if hi.shape[0] < scale * lo.shape[0] or hi.shape[1] < scale * lo.shape[1]:
+        # the reference's crop loop fails with a broadcasting ValueError here (patches.py:67, :136-137)
+        raise ValueError('image of shape %r does not cover %d x the lower-resolution image %r'
+                         % (tuple(hi.shape), scale, tuple(lo.shape)))
+
+
 def get_test_patches(dset_10, dset_20, patchSize=128, border=4, interp=True):
     """utils/patches.py:19-80.  Returns (image_10 [N,B10,P,P], data20 [N,B20,P,P]) float32 ndarrays."""
+    _check_ratio(dset_10, dset_20, 2)
     dev = default_device()
     p_lr, b_lr = patchSize // 2, border // 2
     d10, d20 = _to_device_f32(dset_10, dev), _to_device_f32(dset_20, dev)
@@ -145,6 +153,8 @@ def get_test_patches(dset_10, dset_20, patchSize=128, border=4, interp=True):
 
 def get_test_patches60(dset_10, dset_20, dset_60, patchSize=128, border=8, interp=True):
     """utils/patches.py:83-156.  Returns (image_10, data20, data60) float32 ndarrays."""
+    _check_ratio(dset_10, dset_60, 6)
+    _check_ratio(dset_20, dset_60, 3)
     dev = default_device()
     p20, p60 = patchSize // 2, patchSize // 6
     b20, b60 = border // 2, border // 6

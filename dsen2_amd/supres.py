@@ -8,8 +8,9 @@ _predict(test, input_shape, deep=False, run_60=False)        testing/supres.py:5
 
 The whole chain — symmetric pad + overlapped tiling, mirror-bilinear up-sampling, /2000, the CNN,
 recomposition, *2000 — runs on one MI355X without touching the host between stages; with
-torch.distributed initialised (one process per GPU) the patches are sharded across ranks
-(dsen2_amd/dist.py).  Models are cached per (device, architecture, weight file) instead of being rebuilt
+torch.distributed initialised (one process per GPU, every rank called with the same arrays) the patches are
+sharded across ranks, each rank uploads only the rows its patches read, and the inner crops of the predictions are
+gathered to rank 0, which recomposes and returns the image; every other rank returns None (dsen2_amd/dist.py).  Models are cached per (device, architecture, weight file) instead of being rebuilt
 and re-read on every call as the reference does (supres.py:59,63) — observable behaviour is unchanged.
 """
 from __future__ import division
@@ -69,49 +70,105 @@ def _predict(test, input_shape, deep=False, run_60=False):
     return model.predict(test, verbose=1)
 
 
+def _check_sizes(dsets, scales):
+    """The reference fails with a broadcasting ValueError when the images do not have the 10 m : 20 m (: 60 m) size
+    ratio its crop arithmetic assumes (patches.py:67,136-137); say so before anything reaches the GPU."""
+    lo = dsets[-1].shape
+    for d, s in zip(dsets, scales):
+        if len(d.shape) != 3:
+            raise ValueError('expected HWC images, got shape %r' % (tuple(d.shape),))
+        if d.shape[0] < s * lo[0] or d.shape[1] < s * lo[1]:
+            raise ValueError('image of shape %r does not cover %d x the lowest-resolution image %r'
+                             % (tuple(d.shape), s, tuple(lo)))
+
+
+def _row_slab(org_lr, scale, patch, border, height):
+    """Rows [r0, r1) of one resolution's image that the patches with low-res origins `org_lr` read (the symmetric
+    padding only ever reflects at the true image edges, which a slab touching them shares)."""
+    rows = org_lr[:, 0].astype(np.int64) * scale
+    r0 = max(0, int(rows.min()) - border)
+    r1 = min(int(height), int(rows.max()) - border + patch)
+    return r0, r1
+
+
 def _run(dsets, scales, patch, border, deep, run_60):
+    _check_sizes(dsets, scales)
     dev = _patches.default_device()
-    imgs = [_patches._to_device_f32(d, dev) for d in dsets]
+    rank, world = _dist.rank_world()
     patch_sizes = [patch // (scales[0] // s) for s in scales]          # P, P//2(, P//6)
     borders = [border // (scales[0] // s) for s in scales]             # b, b//2(, b//6)
-    org, n_alloc = _patches.tile_origins(imgs[-1].shape, patch_sizes[-1], borders[-1])
+    org, n_alloc = _patches.tile_origins(dsets[-1].shape, patch_sizes[-1], borders[-1])
     used = org.shape[0]
-    input_shape = tuple((int(d.shape[2]), None, None) for d in imgs)
+    input_shape = tuple((int(d.shape[2]), None, None) for d in dsets)
     model = _get_model(input_shape, deep, run_60)
     cout = model.cout
+    size = dsets[0].shape
     # this rank's contiguous share of the USED patches (the reference's trailing all-zero patches are
     # never read by recompose_images, so they are not computed)
     first, count = _dist.shard_range(used)
-    bs = model.batch_limit(patch, patch)
-    pred_local = torch.empty((count, cout, patch, patch), dtype=torch.float32, device=dev)
-    org_dev = [_patches.device_origins(org, s, dev) for s in scales]   # uploaded once: the loop below only enqueues
-    for i0 in range(0, count, bs):
-        n = min(bs, count - i0)
-        xs = []
-        for k, (img, s, ps, b) in enumerate(zip(imgs, scales, patch_sizes, borders)):
-            if k == 0:
-                # `p10 /= SCALE` (supres.py:23) folded into the gather (IEEE divide, bit-identical)
-                xs.append(_patches.gather_patches_device(img, org, s, b, ps, n_alloc, divisor=SCALE,
-                                                         first=first + i0, count=n, origins_dev=org_dev[k]))
+    per = _dist.per_rank(used, world)
+    inner = patch - 2 * border
+    single = n_alloc == 1            # recompose_images' single-patch shortcut (patches.py:375-376): a[0] uncropped
+    # The buffer this rank's predictions go to.  One rank (or the single-patch case): whole patches.  Several ranks:
+    # the inner crops, in the [per, ...] buffer the gather sends as it is (2.95 GB for a 10980^2 tile over all ranks
+    # instead of 3.85 GB of whole patches to EVERY rank).
+    if world == 1 or single:
+        send = None
+        pred_local = torch.empty((count, cout, patch, patch), dtype=torch.float32, device=dev)
+    else:
+        send = torch.empty((per, cout, inner, inner), dtype=torch.float32, device=dev)
+        pred_local = None
+    if count > 0:
+        # upload only the rows this rank's patches read (1/world of the tile), origins shifted into the slab
+        my_org = org[first:first + count]
+        imgs, org_dev = [], []
+        for d, s, ps, b in zip(dsets, scales, patch_sizes, borders):
+            r0, r1 = _row_slab(my_org, s, ps, b, d.shape[0]) if world > 1 else (0, d.shape[0])
+            imgs.append(_patches._to_device_f32(d[r0:r1], dev))
+            shifted = (my_org * s).astype(np.int32)
+            shifted[:, 0] -= r0
+            org_dev.append(torch.from_numpy(np.ascontiguousarray(shifted)).to(dev))      # uploaded once: the loop only enqueues
+        bs = model.batch_limit(patch, patch)
+        for i0 in range(0, count, bs):
+            n = min(bs, count - i0)
+            xs = []
+            for k, (img, s, ps, b) in enumerate(zip(imgs, scales, patch_sizes, borders)):
+                if k == 0:
+                    # `p10 /= SCALE` (supres.py:23) folded into the gather (IEEE divide, bit-identical)
+                    xs.append(_patches.gather_patches_device(img, my_org, s, b, ps, n_alloc, divisor=SCALE,
+                                                             first=i0, count=n, origins_dev=org_dev[k]))
+                else:
+                    lr = _patches.gather_patches_device(img, my_org, s, b, ps, n_alloc, first=i0, count=n,
+                                                        origins_dev=org_dev[k])
+                    # up-sample raw values, then `/= SCALE` (supres.py:24,43-44)
+                    xs.append(_patches.interp_patches_device(lr, (patch, patch), post_divisor=SCALE))
+            if send is None:
+                model.forward_device(xs, out=pred_local[i0:i0 + n])
             else:
-                lr = _patches.gather_patches_device(img, org, s, b, ps, n_alloc, first=first + i0, count=n,
-                                                    origins_dev=org_dev[k])
-                # up-sample raw values, then `/= SCALE` (supres.py:24,43-44)
-                xs.append(_patches.interp_patches_device(lr, (patch, patch), post_divisor=SCALE))
-        model.forward_device(xs, out=pred_local[i0:i0 + n])
-    size = dsets[0].shape
-    # Everything above is only ENQUEUED (seconds of GPU work for a full tile): the page-locked buffer the result is
-    # downloaded into is allocated now, under that work (0.18 s for a 10980^2 x 6 image; the download itself then
-    # runs at 57 GB/s instead of 11 GB/s from pageable memory: 0.05 s instead of 0.26 s).
-    host = _host_output((int(size[0]), int(size[1]), cout)) if n_alloc > 1 else None
-    pred = _dist.gather_patches(pred_local, used)                      # every rank gets all `used` patches
-    if n_alloc == 1:
-        # recompose_images' single-patch shortcut (patches.py:375-376): a[0] uncropped
-        images = pred[0].permute(1, 2, 0).contiguous() * SCALE
+                y = model.forward_device(xs)
+                send[i0:i0 + n].copy_(y[:, :, border:patch - border, border:patch - border])
+    if single:
+        if rank != 0:
+            return None
+        images = pred_local[0].permute(1, 2, 0).contiguous() * SCALE
         return images.cpu().numpy()
-    print((cout, size[0], size[1]))                                    # patches.py:392
-    # `images *= SCALE` (supres.py:29) folded into the recomposition
-    images = _patches.recompose_device(pred, border, size, scale=SCALE)
+    # Everything above is only ENQUEUED (seconds of GPU work for a full tile): rank 0 allocates the page-locked
+    # buffer the result is downloaded into now, under that work (0.18 s for a 10980^2 x 6 image; the download itself
+    # then runs at 57 GB/s instead of 11 GB/s from pageable memory: 0.05 s instead of 0.26 s).
+    host = _host_output((int(size[0]), int(size[1]), cout)) if rank == 0 else None
+    if world == 1:
+        print((cout, size[0], size[1]))                                # patches.py:392
+        # `images *= SCALE` (supres.py:29) folded into the recomposition
+        images = _patches.recompose_device(pred_local, border, size, scale=SCALE)
+    else:
+        # gather to root: rank 0 receives every rank's inner crops into views of one buffer and recomposes them
+        # (cropped patches of `inner` with border 0 tile exactly like whole patches with their border, patches.py:380-403);
+        # the other ranks return None — no page-locked buffer, no download, nothing received.
+        crops = _dist.gather_to_root(send, used)
+        if rank != 0:
+            return None
+        print((cout, size[0], size[1]))
+        images = _patches.recompose_device(crops, 0, size, scale=SCALE)
     if host is None:
         return images.cpu().numpy()
     host.copy_(images, non_blocking=True)

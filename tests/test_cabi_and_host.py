@@ -101,6 +101,49 @@ def test_tile_origins_reject_images_smaller_than_a_patch():
         tile_origins((50, 50), 64, 4)
 
 
+def test_inconsistent_image_sizes_raise_value_error_before_the_gpu():
+    """The reference fails with a ValueError when the 10 m / 20 m / 60 m images do not have the 2x / 6x size ratio
+    its crop loops assume (patches.py:67,136-137); the drop-in says so up front (crop origins are multiples of the
+    low-resolution ones, so a too-small image would otherwise be read out of bounds)."""
+    from dsen2_amd import patches, supres
+    d20 = np.zeros((120, 120, 6), np.float32)
+    with pytest.raises(ValueError):
+        supres.DSen2_20(np.zeros((200, 240, 4), np.float32), d20)
+    with pytest.raises(ValueError):
+        supres.DSen2_60(np.zeros((240, 240, 4), np.float32), d20, np.zeros((64, 40, 2), np.float32))
+    with pytest.raises(ValueError):
+        patches.get_test_patches(np.zeros((100, 240, 4), np.float32), d20)
+    with pytest.raises(ValueError):
+        patches.get_test_patches60(np.zeros((240, 240, 4), np.float32), np.zeros((100, 120, 6), np.float32),
+                                   np.zeros((40, 40, 2), np.float32))
+    with pytest.raises(ValueError):
+        supres.DSen2_20(np.zeros((240, 240), np.float32), d20)
+
+
+def test_row_slabs_cover_what_a_shard_reads():
+    """Multi-GPU: a rank uploads only rows [r0, r1) of each image; every row its patches read (after the symmetric
+    reflection at the true image edges) must lie inside, and the slab touches an image edge whenever a patch
+    reflects there."""
+    from dsen2_amd import supres
+    from dsen2_amd.patches import tile_origins
+    for (h, w), patch, border in [((300, 300), 64, 4), ((285, 300), 64, 4), ((190, 190), 32, 2)]:
+        org, _ = tile_origins((h, w), patch, border)
+        for world in (1, 2, 3, 8):
+            per = (len(org) + world - 1) // world
+            for r in range(world):
+                mine = org[r * per:(r + 1) * per]
+                if len(mine) == 0:
+                    continue
+                for scale in (1, 2, 6):
+                    H, P, b = h * scale, patch * scale, border * scale
+                    r0, r1 = supres._row_slab(mine, scale, P, b, H)
+                    rows = (mine[:, 0:1].astype(np.int64) * scale - b + np.arange(P)[None, :]).ravel()
+                    refl = np.where(rows < 0, -1 - rows, np.where(rows >= H, 2 * H - 1 - rows, rows))
+                    assert refl.min() >= r0 and refl.max() < r1, (h, patch, world, r, scale)
+                    assert (rows.min() >= 0) or r0 == 0
+                    assert (rows.max() < H) or r1 == H
+
+
 def test_weight_container_matches_oracle_layout(tmp_path):
     from dsen2_amd import weights as w
     for cin, cout, d, f in [(10, 6, 6, 128), (12, 2, 6, 128), (10, 6, 32, 256)]:

@@ -1,5 +1,6 @@
-"""The N>1 path on CPU: world_size-2 gloo processes exercise the sharding arithmetic, the weight
-broadcast (C1) and the output all-gather (C2) of dsen2_amd/dist.py."""
+"""The N>1 path on CPU: world_size-2 and -3 gloo processes exercise the sharding arithmetic, the weight
+broadcast (C1) and the gather of outputs to rank 0 (C2) of dsen2_amd/dist.py, including uneven shards and a rank
+with nothing to do."""
 import os
 import socket
 import sys
@@ -44,28 +45,35 @@ def _worker(rank, world, port, total, q):
         flat = np.arange(1000, dtype=np.float32) * 0.5 if rank == 0 else None
         got = dist.broadcast_weights(flat, 1000)
         ok = np.array_equal(got, np.arange(1000, dtype=np.float32) * 0.5)
-        # C2: each rank "predicts" its shard with a stand-in computation (patch index encoded in the data)
+        # C2: each rank "predicts" its shard with a stand-in computation (patch index encoded in the data) straight
+        # into the [per, ...] buffer the gather sends; only rank 0 receives
         first, count = dist.shard_range(total)
-        local = torch.stack([torch.full((2, 4, 4), float(first + i)) for i in range(count)]) if count else \
-            torch.zeros((0, 2, 4, 4))
-        full = dist.gather_patches(local, total)
-        ok = ok and full.shape == (total, 2, 4, 4)
-        ok = ok and all(float(full[i, 0, 0, 0]) == float(i) and float(full[i, 1, 3, 3]) == float(i) for i in range(total))
+        per = dist.per_rank(total, world)
+        send = torch.full((per, 2, 4, 4), -1.0)
+        for i in range(count):
+            send[i] = float(first + i)
+        full = dist.gather_to_root(send, total)
+        if rank == 0:
+            ok = ok and full is not None and full.shape == (total, 2, 4, 4)
+            ok = ok and all(float(full[i, 0, 0, 0]) == float(i) and float(full[i, 1, 3, 3]) == float(i) for i in range(total))
+        else:
+            ok = ok and full is None
         q.put((rank, bool(ok)))
     finally:
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize('total', [9, 2, 1])
-def test_broadcast_and_gather_world2(total):
+@pytest.mark.parametrize('world,total', [(2, 9), (2, 2), (2, 1), (3, 7), (3, 2)])
+def test_broadcast_and_gather_to_root(world, total):
+    """(3, 7): uneven shards 3 + 3 + 1; (3, 2) and (2, 1): the last rank has no patch at all."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    res = dict(q.get(timeout=10) for _ in range(2))
-    assert res == {0: True, 1: True}
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res == {r: True for r in range(world)}

@@ -2,6 +2,7 @@
 timing, one JSON line from rank 0) rehearsed with 2 ranks on ONE GPU over gloo.  Not a measurement."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -11,9 +12,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
 def test_bench_two_ranks_gloo_rehearsal():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+           '127.0.0.1', '--master-port', _free_port(), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
            '--warmup', '1', '--batch', '64', '--backend', 'gloo']
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -37,12 +46,23 @@ def test_bench_single_gpu_line_has_contract_fields():
 
 
 def test_full_tile_two_ranks_gloo_matches_single_rank():
-    """supres._run patch sharding + dist.gather_patches with 2 ranks (gloo, both on the one GPU): the image every
-    rank returns equals the single-rank image bit for bit."""
+    """supres._run patch sharding + slab uploads + dist.gather_to_root with 2 ranks (gloo, both on the one GPU): the
+    image rank 0 returns equals the single-rank image bit for bit; rank 1 returns None."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', '29733', os.path.join(ROOT, 'tools', 'bench_full_tile.py'), '--size', '600',
+           '127.0.0.1', '--master-port', _free_port(), os.path.join(ROOT, 'tools', 'bench_full_tile.py'), '--size', '600',
            '--skip60', '--backend', 'gloo', '--check']
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
     assert r['n_gpus'] == 2 and r['patches20'] == 36 and r['matches_single_rank'] is True
+
+
+def test_full_tile_three_ranks_gloo_uneven_shards():
+    """3 ranks over 36 patches of a non-dividing tile size (uneven shards, ragged last tile row/column)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr',
+           '127.0.0.1', '--master-port', _free_port(), os.path.join(ROOT, 'tools', 'bench_full_tile.py'), '--size', '570',
+           '--skip60', '--backend', 'gloo', '--check']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert r['n_gpus'] == 3 and r['matches_single_rank'] is True

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE configs[3]: DSen2_20 + DSen2_60 over a synthetic full-size Sentinel-2 tile (10980 x 10980 @10 m),
 end to end through the drop-in surface (host ndarray in, host ndarray out), on one GPU or patch-sharded over the
-GPUs of a node (one process per GPU, RCCL all-gather of the predictions: dsen2_amd/dist.py).
+GPUs of a node (one process per GPU; the inner crops of the predictions are gathered to rank 0 over RCCL, which
+recomposes and returns the image — every other rank gets None: dsen2_amd/dist.py).
 
     python tools/bench_full_tile.py [--size 10980] [--skip60]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_full_tile.py
@@ -30,6 +31,7 @@ ap.add_argument('--size', type=int, default=10980)
 ap.add_argument('--skip60', action='store_true')
 ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'])
 ap.add_argument('--check', action='store_true', help='multi-rank: also verify the result against a single-rank run')
+ap.add_argument('--port', type=int, default=0, help=argparse.SUPPRESS)
 args = ap.parse_args()
 
 import torch.distributed as td      # noqa: E402
@@ -69,24 +71,36 @@ def timed(fn, *a):
 with contextlib.redirect_stdout(io.StringIO()):
     supres.DSen2_20(d10[:240, :240], d20[:120, :120])       # warm-up: library load, model build, weight upload
 y20, t20 = timed(supres.DSen2_20, d10, d20)
+if world > 1:                       # whole-job wall time: the slowest rank's
+    tt = torch.tensor([t20], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+    td.all_reduce(tt, op=td.ReduceOp.MAX)
+    t20 = float(tt.item())
 out['dsen2_20_s'] = round(t20, 3)
 out['dsen2_20_patches_per_s_128'] = round(out['patches20'] / t20, 1)
 out['dsen2_20_equiv_32x32_patches_per_s'] = round(out['patches20'] * 16 / t20, 1)
-assert y20.shape == (n, n, 6) and np.isfinite(y20[::97, ::89]).all()
+if rank == 0:
+    assert y20.shape == (n, n, 6) and np.isfinite(y20[::97, ::89]).all()
+else:
+    assert y20 is None              # only rank 0 receives, recomposes and downloads
 if not args.skip60:
     with contextlib.redirect_stdout(io.StringIO()):
         supres.DSen2_60(d10[:384, :384], d20[:192, :192], d60[:64, :64])
     y60, t60 = timed(supres.DSen2_60, d10, d20, d60)
+    if world > 1:
+        tt = torch.tensor([t60], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        t60 = float(tt.item())
     out['dsen2_60_s'] = round(t60, 3)
     out['dsen2_60_equiv_32x32_patches_per_s'] = round(out['patches60'] * 36 / t60, 1)
-    assert y60.shape == (n, n, 2)
+    assert (y60.shape == (n, n, 2)) if rank == 0 else (y60 is None)
 out['peak_gpu_mem_gib'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
 if world > 1 and args.check:
     td.barrier()
     td.destroy_process_group()            # dist.rank_world() now reports (0, 1): every rank computes everything
-    with contextlib.redirect_stdout(io.StringIO()):
-        ref = supres.DSen2_20(d10, d20)
-    out['matches_single_rank'] = bool(np.array_equal(ref, y20))
+    if rank == 0:
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = supres.DSen2_20(d10, d20)
+        out['matches_single_rank'] = bool(np.array_equal(ref, y20))
 if rank == 0:
     print(json.dumps(out))
 if world > 1 and td.is_initialized():
