@@ -207,10 +207,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'dsen2_20_fp32':
         # ---- CPU baseline: the same graph on the host cores, bounded sample (oracle/ = checker code) ----
         from oracle import cpu_graph
-        pps, sample, cores, y_cpu = cpu_graph.time_patches_per_s(flat, xs_np, NUM_LAYERS, FEAT, budget_s=args.cpu_budget)
+        pps, sample, cores, y_cpu, gflops = cpu_graph.time_patches_per_s(flat, xs_np, NUM_LAYERS, FEAT, budget_s=args.cpu_budget)
         result['cpu_baseline'] = {'value': round(pps, 2), 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
-                                  'sample': '%d patches of the same synthetic batch, torch-CPU fp32 conv2d graph '
-                                            '(oneDNN), ~%.0f s' % (sample, args.cpu_budget)}
+                                  'gflops': round(gflops, 1), 'cpu': cpu_graph.cpu_model_name(),
+                                  'sample': 'the first 64 patches of the same synthetic batch, run repeatedly as ONE fixed '
+                                            'batch (%d patches timed in ~%.0f s, two warm-up passes excluded); '
+                                            'torch-CPU fp32 conv2d graph (oneDNN), one thread per physical core'
+                                            % (sample, args.cpu_budget)}
         n = y_cpu.shape[0]
         diff = out[:n].cpu().numpy().astype(np.float64) - y_cpu.astype(np.float64)
         result['rmse_vs_cpu_fp32'] = float(np.sqrt(np.mean(diff * diff)))

@@ -84,8 +84,9 @@ class S2Model(object):
                     x.device != self.device:
                 raise ValueError('input must be a contiguous float32 %s tensor of shape %r, got %r %s %s'
                                  % (self.device, (n, c, h, w), tuple(x.shape), x.dtype, x.device))
-        if out is None:
-            out = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=self.device)
+        out = self._check_out(out, n, h, w)
+        if n == 0:
+            return out
         ws = self._get_workspace(self.workspace_bytes(n, h, w))
         with torch.cuda.device(self.device):
             _lib.call('dsen2_model_forward', self._handle, _ptr(xs[0]), _ptr(xs[1]),
@@ -93,13 +94,24 @@ class S2Model(object):
                       _ptr(ws), ws.numel(), _stream_ptr(self.device))
         return out
 
+    def _check_out(self, out, n, h, w):
+        """The raw pointer of `out` goes straight to the kernels: a wrong-sized, strided or other-device tensor
+        would be written out of bounds or in the wrong place."""
+        if out is None:
+            return torch.empty((n, self.cout, h, w), dtype=torch.float32, device=self.device)
+        if tuple(out.shape) != (n, self.cout, h, w) or out.dtype != torch.float32 or not out.is_contiguous() or \
+                out.device != self.device:
+            raise ValueError('out must be a contiguous float32 %s tensor of shape %r, got %r %s %s (contiguous: %s)'
+                             % (self.device, (n, self.cout, h, w), tuple(out.shape), out.dtype, out.device,
+                                out.is_contiguous()))
+        return out
+
     def time_body_in_forward(self, xs, out=None, iters=10):
         """Mean duration (ms) of ONE residual-block convolution launch inside `iters` full forward passes on `xs`
         (HIP events on the launch stream around the 2*num_layers body convolutions of each pass): the duration the
         kernel has in the running network — bench.py's roofline measurement."""
         n, _, h, w = xs[0].shape
-        if out is None:
-            out = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=self.device)
+        out = self._check_out(out, n, h, w)
         ws = self._get_workspace(self.workspace_bytes(n, h, w))
         ms = ctypes.c_float(0)
         with torch.cuda.device(self.device):
@@ -116,8 +128,9 @@ class S2Model(object):
         """keras Model.predict: list of NCHW float32 ndarrays -> ndarray [N, cout, H, W].
 
         ``batch_size`` only bounds device memory (results do not depend on it); default: as many
-        patches as fit ``max_workspace_bytes``.  With more than one batch the host<->device copies are pipelined:
-        batch i+1 is staged (page-locked buffer, copy stream) and batch i-1 is downloaded while batch i computes.
+        patches as fit ``max_workspace_bytes``.  Host<->device copies go through page-locked buffers on their own
+        streams; with more than one batch, batch i+1 is staged and batch i-1 downloaded while batch i computes.
+        A model's workspace is one buffer: use a model from one stream / thread at a time.
         """
         xs = [np.ascontiguousarray(a, dtype=np.float32) for a in x]
         if len(xs) != len(self.bands):
@@ -128,19 +141,18 @@ class S2Model(object):
                 raise ValueError('input of shape %r where %r is expected' % (a.shape, (n, c, h, w)))
         bs = self.batch_limit(h, w) if batch_size is None else int(batch_size)
         out = np.empty((n, self.cout, h, w), np.float32)
-        starts = list(range(0, n, bs))
-        if len(starts) <= 1:
-            for i0 in starts:
-                dev = [torch.from_numpy(a[i0:n]).to(self.device, non_blocking=False) for a in xs]
-                out[i0:n] = self.forward_device(dev).cpu().numpy()
-                self._progress(verbose, n, n)
+        if n == 0:
             return self._progress_end(verbose, out)
-
+        starts = list(range(0, n, bs))
+        bs = min(bs, n)
         with torch.cuda.device(self.device):
             comp = torch.cuda.current_stream(self.device)
             h2d, d2h = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+            # one slot for a single batch, two to overlap staging / compute / download of consecutive batches; every
+            # transfer goes through page-locked memory on its own stream (a pageable copy blocks the host and runs at
+            # a fifth of the PCIe rate)
             slots = []
-            for _ in range(2):
+            for _ in range(min(2, len(starts))):
                 slots.append(dict(
                     pin_in=[torch.empty((bs, c, h, w), dtype=torch.float32, pin_memory=True) for c in self.bands],
                     dev_in=[torch.empty((bs, c, h, w), dtype=torch.float32, device=self.device) for c in self.bands],
@@ -159,7 +171,7 @@ class S2Model(object):
             for i, i0 in enumerate(starts):
                 i1 = min(n, i0 + bs)
                 m = i1 - i0
-                slot = slots[i & 1]
+                slot = slots[i % len(slots)]
                 collect(slot)                       # batch i-2: after this the slot's buffers are all free
                 for k, a in enumerate(xs):          # host copy into page-locked memory, under batch i-1's compute
                     slot['pin_in'][k][:m].numpy()[...] = a[i0:i1]
@@ -176,8 +188,9 @@ class S2Model(object):
                     slot['ev_out'].record(d2h)
                 slot['span'] = (i0, i1)
             last = len(starts) - 1
-            collect(slots[(last - 1) & 1])
-            collect(slots[last & 1])
+            if len(slots) > 1:
+                collect(slots[(last - 1) % 2])
+            collect(slots[last % len(slots)])
         return self._progress_end(verbose, out)
 
     @staticmethod

@@ -1,16 +1,24 @@
-"""GDAL-free command line for the drop-in path: the super-resolution part of the reference's
-testing/s2_tiles_supres.py (:332-342 the DSen2_60 / DSen2_20 calls, :383-420 band assembly and the npz writer)
-with arrays read from a .npz (or MATLAB v7.3 .mat when h5py is importable) instead of a SAFE product.
+"""Command line for the drop-in path: the super-resolution flow of the reference's testing/s2_tiles_supres.py.
 
-    python -m dsen2_amd.cli INPUT OUTPUT.npz [--run_60] [--copy_original_bands] [--roi_x_y x1,y1,x2,y2]
-                                            [--models DIR] [--save_prefix P] [--precision fp32|bf16] [--deep]
+    python -m dsen2_amd.cli INPUT [OUTPUT] [--run_60] [--copy_original_bands] [--roi_x_y x1,y1,x2,y2]
+                                  [--output_file_format GTiff|ENVI|...|npz] [--select_UTM ZONE] [--save_prefix P]
+                                  [--bands10 B4,B3,B2,B8] [--models DIR] [--precision fp32|bf16] [--deep]
 
-INPUT .npz keys: data10 [x,y,4] (B2,B3,B4,B8), data20 [x/2,y/2,6] (B5,B6,B7,B8A,B11,B12), data60 [x/6,y/6,2]
-(B1,B9) — the arrays s2_tiles_supres.py:311-329 reads from GDAL; aliases d10/d20/d60 and im10/im20/im60 (the
-keys of the reference's data/*.mat, CHW, transposed like testing/demoDSen2.py:14-28) are accepted.
-OUTPUT: np.savez(output, bands={description: 2-D array}) exactly like the reference's npz fallback (:419-420),
-band descriptions "SR" + name.  Users with GDAL keep using the reference's own script: it only needs
-`from supres import DSen2_20, DSen2_60` to resolve to dsen2_amd.supres.
+Two kinds of INPUT:
+  * an array file — .npz with keys data10 [x,y,4], data20 [x/2,y/2,6], data60 [x/6,y/6,2] (aliases d10/d20/d60),
+    or a MATLAB v7.3 .mat with im10/im20/im60 as in the reference's data/*.mat (needs h5py; CHW, transposed like
+    testing/demoDSen2.py:14-28).  Output: np.savez(output, bands={description: 2-D array}) exactly like the
+    reference's npz fallback (s2_tiles_supres.py:419-420).
+  * anything else (a Sentinel-2 .zip / SAFE .xml) is opened with GDAL when `osgeo` is importable: sub-dataset and
+    band selection, ROI rounding, ReadAsArray into HWC (s2_tiles_supres.py:102-329) and the GTiff/ENVI writer with
+    the geo-transform shifted to the ROI (:371-413); a format GDAL cannot create falls back to npz (:350-360).
+    Without `osgeo` this branch says so and exits; the reference's own script also keeps working unchanged, it only
+    needs `from supres import DSen2_20, DSen2_60` to resolve to dsen2_amd.supres.
+
+CHANNEL ORDER.  The 10 m array is in the order of the SAFE product's 10 m sub-dataset, which is what
+s2_tiles_supres.py reads and what the checkpoints were trained on: B4, B3, B2, B8 (red, green, blue, NIR).
+`--copy_original_bands` labels the channels with that list; an array file in another order says so with
+--bands10 (or a `bands10` entry in the .npz).  20 m: B5 B6 B7 B8A B11 B12; 60 m: B1 B9 (B10 is not super-resolved).
 """
 from __future__ import division
 
@@ -24,6 +32,7 @@ import numpy as np
 BANDS10 = ['B4', 'B3', 'B2', 'B8']            # order of the 10 m sub-dataset in a SAFE product
 BANDS20 = ['B5', 'B6', 'B7', 'B8A', 'B11', 'B12']
 BANDS60 = ['B1', 'B9']
+ARRAY_EXTENSIONS = ('.npz', '.mat')
 
 
 def _load(path):
@@ -47,14 +56,129 @@ def _load(path):
     raise ValueError('unsupported input %r (use .npz or .mat)' % path)
 
 
+def snap_roi(x1, y1, x2, y2, width, height):
+    """s2_tiles_supres.py:111-120 — ROI clipped to the raster and grown to 60 m pixel boundaries (10 m pixels)."""
+    xmin = max(min(x1, x2, width - 1), 0)
+    xmax = min(max(x1, x2, 0), width - 1)
+    ymin = max(min(y1, y2, height - 1), 0)
+    ymax = min(max(y1, y2, 0), height - 1)
+    return int(xmin / 6) * 6, int(ymin / 6) * 6, int((xmax + 1) / 6) * 6 - 1, int((ymax + 1) / 6) * 6 - 1
+
+
+def short_band_name(description):
+    """s2_tiles_supres.py:243-248 — 'B4, central wavelength 665 nm' -> 'B4'."""
+    for sep in (',', ' '):
+        if sep in description:
+            return description[:description.find(sep)]
+    return description[:3]
+
+
+def tidy_description(description, fmt):
+    """s2_tiles_supres.py:217-225 — band descriptions as the reference writes them."""
+    m = re.match(r'(.*?), central wavelength (\d+) nm', description)
+    if m:
+        return m.group(1) + ' (' + m.group(2) + ' nm)'
+    if fmt == 'ENVI' and ',' in description:       # ENVI band names must not contain commas
+        pos = description.find(',')
+        return description[:pos] + description[pos + 1:]
+    return description
+
+
+class GdalProduct(object):
+    """The GDAL side of s2_tiles_supres.py for one product: which sub-datasets and bands, the ROI, the arrays."""
+
+    def __init__(self, gdal, path, want, roi_x_y=None, select_utm='', fmt='GTiff'):
+        self.gdal, self.fmt = gdal, fmt
+        raster = gdal.Open(path)
+        if raster is None:
+            raise OSError('GDAL cannot open %r' % path)
+        groups = {'10m': [], '20m': [], '60m': [], 'other': []}
+        for name, desc in raster.GetSubDatasets():
+            key = next((k for k in ('10m', '20m', '60m') if (k + ' resolution') in desc), 'other')
+            groups[key].append((name, desc))
+        tens = groups['10m'] or groups['other']
+        if not tens or not groups['20m']:
+            raise ValueError('no 10 m / 20 m sub-dataset in %r' % path)
+        # several UTM zones in one product: the requested one, else the one whose ROI covers most pixels (:102-187)
+        best = None
+        for idx, (name, desc) in enumerate(tens):
+            ds = gdal.Open(name)
+            w, h = ds.RasterXSize, ds.RasterYSize
+            box = snap_roi(roi_x_y[0], roi_x_y[1], roi_x_y[2], roi_x_y[3], w, h) if roi_x_y else (0, 0, w - 1, h - 1)
+            utm = desc[desc.find('UTM'):] if 'UTM' in desc else ''
+            area = (box[2] - box[0] + 1) * (box[3] - box[1] + 1)
+            if select_utm and utm == select_utm:
+                best = (area, idx, box, utm)
+                break
+            if best is None or area > best[0]:
+                best = (area, idx, box, utm)
+        _, idx, (self.xmin, self.ymin, self.xmax, self.ymax), self.utm = best
+        if self.xmax < self.xmin or self.ymax < self.ymin:
+            raise ValueError('Invalid region of interest / UTM Zone combination')
+
+        def same_zone(cands):
+            hit = [c for c in cands if self.utm and self.utm in c[1]]
+            return (hit or cands[idx:idx + 1] or cands[:1] or [None])[0]
+        self.ds = {'10m': gdal.Open(tens[idx][0]), '20m': gdal.Open(same_zone(groups['20m'])[0])}
+        s60 = same_zone(groups['60m'])
+        self.ds['60m'] = gdal.Open(s60[0]) if s60 else None
+        # bands by short name, in sub-dataset order; a name is consumed once (:257-292)
+        want = list(want)
+        self.names, self.index, self.descriptions = {}, {}, {}
+        for key in ('10m', '20m', '60m'):
+            self.names[key], self.index[key] = [], []
+            ds = self.ds[key]
+            for b in range(ds.RasterCount if ds is not None else 0):
+                desc = tidy_description(ds.GetRasterBand(b + 1).GetDescription(), fmt)
+                sn = short_band_name(desc)
+                if sn in want:
+                    want.remove(sn)
+                    self.names[key].append(sn)
+                    self.index[key].append(b)
+                    self.descriptions[sn] = desc
+
+    def read(self, key):
+        """HWC array of the selected bands of one resolution, ROI applied (:311-329)."""
+        if not self.index[key]:
+            return None
+        div = {'10m': 1, '20m': 2, '60m': 6}[key]
+        xs, ys = (self.xmax - self.xmin + 1) // div, (self.ymax - self.ymin + 1) // div
+        a = self.ds[key].ReadAsArray(xoff=self.xmin // div, yoff=self.ymin // div, xsize=xs, ysize=ys,
+                                     buf_xsize=xs, buf_ysize=ys)
+        a = np.asarray(a)
+        if a.ndim == 2:
+            a = a[None]
+        return np.moveaxis(a, 0, 2)[:, :, self.index[key]]
+
+    def writer(self, path, width, height, nbands):
+        """A GDAL dataset to write `nbands` float64 bands into, geo-referenced to the ROI (:371-382); None when the
+        driver cannot create files (the caller then falls back to npz, :350-360)."""
+        gdal = self.gdal
+        driver = gdal.GetDriverByName(self.fmt)
+        meta = driver.GetMetadata() if driver else {}
+        if not driver or meta.get(gdal.DCAP_CREATE) != 'YES':
+            return None
+        out = driver.Create(path, width, height, nbands, gdal.GDT_Float64)
+        geot = list(self.ds['10m'].GetGeoTransform())
+        geot[0] += self.xmin * 10          # upper-left corner moves with the ROI: 10 m per pixel
+        geot[3] -= self.ymin * 10
+        out.SetGeoTransform(tuple(geot))
+        out.SetProjection(self.ds['10m'].GetProjection())
+        return out
+
+
 def main(argv=None):
-    ap = argparse.ArgumentParser(description='Perform super-resolution on Sentinel-2 arrays with DSen2 on MI355X.')
+    ap = argparse.ArgumentParser(description='Perform super-resolution on Sentinel-2 with DSen2 on MI355X.')
     ap.add_argument('data_file')
     ap.add_argument('output_file', nargs='?')
     ap.add_argument('--roi_x_y', default='', help='x_1,y_1,x_2,y_2 on the 10m bands; extended to 60m pixel boundaries')
     ap.add_argument('--run_60', action='store_true', help='also super-resolve the 60m bands (B1,B9)')
     ap.add_argument('--copy_original_bands', action='store_true')
     ap.add_argument('--save_prefix', default='')
+    ap.add_argument('--output_file_format', default=None, help='GDAL driver name (GDAL input: default GTiff) or npz')
+    ap.add_argument('--select_UTM', default='', help='GDAL input: UTM zone to use (default: largest ROI coverage)')
+    ap.add_argument('--bands10', default=None,
+                    help='array input: names of the 10 m channels in the order they are stored (default B4,B3,B2,B8)')
     ap.add_argument('--models', default=None, help='directory with the checkpoints (default: supres.MDL_PATH)')
     ap.add_argument('--deep', action='store_true', help='VDSen2 (d=32, F=256)')
     ap.add_argument('--precision', default=None, choices=['fp32', 'bf16'])
@@ -66,23 +190,61 @@ def main(argv=None):
     if args.precision:
         supres.PRECISION = args.precision
 
-    data10, data20, data60 = _load(args.data_file)
-    if data10 is None or data20 is None:
-        print('No super-resolution performed, exiting')          # s2_tiles_supres.py:346-348
-        return 0
-    if args.roi_x_y:
-        x1, y1, x2, y2 = [int(float(v)) for v in re.split(',', args.roi_x_y)]
-        xmin, xmax, ymin, ymax = min(x1, x2), max(x1, x2), min(y1, y2), max(y1, y2)
-        # nearest 60 m pixel boundaries, as s2_tiles_supres.py:131-134
-        xmin, ymin = int(xmin / 6) * 6, int(ymin / 6) * 6
-        xmax, ymax = int((xmax + 1) / 6) * 6 - 1, int((ymax + 1) / 6) * 6 - 1
-        data10 = data10[ymin:ymax + 1, xmin:xmax + 1]
-        data20 = data20[ymin // 2:(ymax + 1) // 2, xmin // 2:(xmax + 1) // 2]
-        if data60 is not None:
-            data60 = data60[ymin // 6:(ymax + 1) // 6, xmin // 6:(xmax + 1) // 6]
+    roi = [float(v) for v in re.split(',', args.roi_x_y)] if args.roi_x_y else None
+    product = None
+    is_array = os.path.splitext(args.data_file)[1].lower() in ARRAY_EXTENSIONS
+    if is_array:
+        data10, data20, data60 = _load(args.data_file)
+        if data10 is None or data20 is None:
+            print('No super-resolution performed, exiting')          # s2_tiles_supres.py:346-348
+            return 0
+        names10 = list(BANDS10)
+        if args.bands10:
+            names10 = [b.strip() for b in args.bands10.split(',')]
+        elif args.data_file.lower().endswith('.npz') and 'bands10' in np.load(args.data_file):
+            names10 = [str(b) for b in np.load(args.data_file)['bands10']]
+        if len(names10) < data10.shape[2]:
+            raise ValueError('%d names for %d 10 m channels' % (len(names10), data10.shape[2]))
+        names10, names20, names60 = names10[:data10.shape[2]], list(BANDS20), list(BANDS60)
+        descriptions = dict((b, b) for b in names10 + names20 + names60)
+        if roi:
+            xmin, ymin, xmax, ymax = snap_roi(roi[0], roi[1], roi[2], roi[3], data10.shape[1], data10.shape[0])
+            data10 = data10[ymin:ymax + 1, xmin:xmax + 1]
+            data20 = data20[ymin // 2:(ymax + 1) // 2, xmin // 2:(xmax + 1) // 2]
+            if data60 is not None:
+                data60 = data60[ymin // 6:(ymax + 1) // 6, xmin // 6:(xmax + 1) // 6]
+        fmt = 'npz'
+        default_out = os.path.split(args.data_file)[1] + '.npz'
+    else:
+        try:
+            from osgeo import gdal
+        except ImportError:
+            print('%s is not an array file (.npz / .mat) and GDAL (osgeo) is not importable: convert the product to '
+                  '.npz (keys data10, data20, data60), or run the reference script with the supres shim of '
+                  'INTEGRATION.md' % args.data_file)
+            return 2
+        fmt = args.output_file_format or 'GTiff'
+        want = 'B1,B2,B3,B4,B5,B6,B7,B8,B8A,B9,B11,B12' if args.run_60 else 'B2,B3,B4,B5,B6,B7,B8,B8A,B11,B12'
+        try:
+            product = GdalProduct(gdal, args.data_file, want.split(','), roi, args.select_UTM, fmt)
+        except ValueError as e:
+            print(e)
+            return 0                                               # the reference exits 0 here too (:196-198)
+        print('Selected UTM Zone:', product.utm)
+        print('Selected pixel region: xmin=%d, ymin=%d, xmax=%d, ymax=%d:' % (product.xmin, product.ymin, product.xmax, product.ymax))
+        data10, data20, data60 = product.read('10m'), product.read('20m'), product.read('60m')
+        names10, names20, names60 = product.names['10m'], product.names['20m'], product.names['60m']
+        descriptions = product.descriptions
+        if data10 is None or data20 is None:
+            print('No super-resolution performed, exiting')
+            return 0
+        default_out = os.path.split(args.data_file)[1] + '.tif'
+    if args.output_file_format == 'npz':
+        fmt = 'npz'
 
-    output_file = args.output_file or os.path.split(args.data_file)[1] + '.npz'
-    output_file = args.save_prefix + output_file
+    output_file = args.save_prefix + (args.output_file or default_out)
+    if fmt == 'ENVI' and output_file[-4:].lower() == '.hdr':
+        output_file = output_file[:-4] + '.bin'                    # ENVI wants the .bin name (:305-307)
 
     sr60 = None
     if args.run_60 and data60 is not None:
@@ -90,24 +252,42 @@ def main(argv=None):
         sr60 = supres.DSen2_60(data10, data20, data60, deep=args.deep)
     print('Super-resolving the 20m data into 10m bands')
     sr20 = supres.DSen2_20(data10, data20, deep=args.deep)
+    if sr20 is None:                                               # a rank other than 0 of a multi-GPU run
+        return 0
 
-    bands = dict()
     if sr60 is not None:
-        sr = np.concatenate((sr20, sr60), axis=2)
-        names = BANDS20 + BANDS60
+        sr, sr_names = np.concatenate((sr20, sr60), axis=2), names20 + names60
     else:
-        sr, names = sr20, BANDS20
+        sr, sr_names = sr20, names20
+    planes = []                                                    # (description, 2-D array) in output order
+    if args.copy_original_bands:
+        planes += [(descriptions[bn], data10[:, :, bi]) for bi, bn in enumerate(names10)]
+    planes += [('SR' + descriptions[bn], sr[:, :, bi]) for bi, bn in enumerate(sr_names)]
+
+    dataset = None
+    if fmt != 'npz':
+        dataset = product.writer(output_file, data10.shape[1], data10.shape[0], len(planes))
+        if dataset is None:
+            print("Gdal doesn't support creating %s files" % fmt)
+            print('Writing to npz as a fallback')
+            fmt = 'npz'
     sys.stdout.write('Writing')
     if args.copy_original_bands:
         sys.stdout.write(' the original 10m bands and')
-        for bi, bn in enumerate(BANDS10[:data10.shape[2]]):
-            bands[bn] = data10[:, :, bi]
     print(' the super-resolved bands in %s' % output_file)
-    for bi, bn in enumerate(names):
-        bands['SR' + bn] = sr[:, :, bi]
-    for desc in bands:
+    if fmt == 'npz':
+        bands = dict()
+        for desc, plane in planes:
+            bands[desc] = plane
+        np.savez(output_file, bands=bands)
+    else:
+        for i, (desc, plane) in enumerate(planes):
+            band = dataset.GetRasterBand(i + 1)
+            band.SetDescription(desc)
+            band.WriteArray(plane)
+        dataset.FlushCache()
+    for desc, _ in planes:
         print(desc)
-    np.savez(output_file, bands=bands)
     return 0
 
 

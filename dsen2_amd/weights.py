@@ -44,21 +44,39 @@ def _from_keras_hdf5(path, shapes):
     except ImportError as e:   # pragma: no cover - depends on the host
         raise ImportError('reading a keras .hdf5 checkpoint needs h5py; convert it once with '
                           'tools/convert_keras_hdf5.py on a machine that has h5py and load the .npy') from e
+    import re
     parts = []
     with h5py.File(path, 'r') as f:
         root = f['model_weights'] if 'model_weights' in f else f
-        names = [n.decode() if isinstance(n, bytes) else n for n in root.attrs['layer_names']]
+        _s = lambda n: n.decode() if isinstance(n, bytes) else str(n)
+        names = [_s(n) for n in root.attrs['layer_names']] if 'layer_names' in root.attrs else list(root.keys())
         convs = []
         for lname in names:
             grp = root[lname]
-            wn = [n.decode() if isinstance(n, bytes) else n for n in grp.attrs.get('weight_names', [])]
-            if len(wn) == 2:
-                convs.append((np.asarray(grp[wn[0]]), np.asarray(grp[wn[1]])))
+            wn = [_s(n) for n in grp.attrs.get('weight_names', [])]
+            if not wn:
+                continue                       # Input / Concatenate / Activation / Lambda / Add carry no weights
+            # a Conv2D holds exactly '<layer>/kernel:0' and '<layer>/bias:0' — picked by NAME, not by position
+            kern = [n for n in wn if n.split('/')[-1].startswith('kernel')]
+            bias = [n for n in wn if n.split('/')[-1].startswith('bias')]
+            if len(wn) != 2 or len(kern) != 1 or len(bias) != 1:
+                raise ValueError('%s: layer %r holds weights %r, expected one kernel and one bias' % (path, lname, wn))
+            for n in wn:
+                if n.split('/')[0] != lname:
+                    raise ValueError('%s: weight %r does not belong to layer %r' % (path, n, lname))
+            m = re.search(r'(\d+)$', lname)
+            convs.append((int(m.group(1)) if m else len(convs), lname, np.asarray(grp[kern[0]]), np.asarray(grp[bias[0]])))
+        # Graph order (utils/DSen2Net.py:29-35) is the order the Conv2D layers were created = their numeric suffix
+        # (conv2d_7, conv2d_8, ... when other models were built in the same session); the attribute order of an HDF5
+        # file is not something to rely on
+        convs.sort(key=lambda c: c[0])
+        if len(set(c[0] for c in convs)) != len(convs):
+            raise ValueError('%s: conv layer names %r have no unique numeric order' % (path, [c[1] for c in convs]))
         if len(convs) != len(shapes):
             raise ValueError('%s holds %d conv layers, the architecture has %d' % (path, len(convs), len(shapes)))
-        for (k, b), (a, o) in zip(convs, shapes):
+        for (_, lname, k, b), (a, o) in zip(convs, shapes):
             if k.shape != (3, 3, a, o) or b.shape != (o,):
-                raise ValueError('layer shape %s/%s does not match (3,3,%d,%d)' % (k.shape, b.shape, a, o))
+                raise ValueError('layer %s: shape %s/%s does not match (3,3,%d,%d)' % (lname, k.shape, b.shape, a, o))
             parts += [k.astype(np.float32).ravel(), b.astype(np.float32)]
     return np.concatenate(parts)
 

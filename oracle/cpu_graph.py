@@ -31,26 +31,52 @@ def forward(layers, xs, num_layers):
     return F.conv2d(x, layers[-1][0], layers[-1][1], padding=1) + xs[-1]
 
 
-def time_patches_per_s(flat, xs_np, num_layers, feature_size, budget_s=15.0, threads=None):
-    """Run the graph on growing samples of xs_np until ~budget_s of CPU work; return (patches/s, sample, cores)."""
-    if threads:
-        torch.set_num_threads(threads)
+def cpu_model_name():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def physical_cores():
+    """Physical cores available to this process (SMT siblings counted once, cgroup/affinity limits respected)."""
+    try:
+        import os
+        avail = os.sched_getaffinity(0)
+        seen = set()
+        for c in avail:
+            try:
+                sib = open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c).read().strip()
+            except OSError:
+                sib = str(c)
+            seen.add(sib)
+        return max(1, len(seen))
+    except Exception:
+        return max(1, torch.get_num_threads())
+
+
+def time_patches_per_s(flat, xs_np, num_layers, feature_size, budget_s=15.0, threads=None, batch=64):
+    """The graph on a FIXED batch of `batch` patches of xs_np, warm-up excluded, repeated until ~budget_s of CPU
+    work: (patches/s, patches timed, threads used, last output, GFLOP/s)."""
+    torch.set_num_threads(int(threads) if threads else physical_cores())
     cores = torch.get_num_threads()
     cin = sum(a.shape[1] for a in xs_np)
     cout = xs_np[-1].shape[1]
     layers = build(flat, cin, cout, num_layers, feature_size)
-    n = 4
+    n = min(batch, xs_np[0].shape[0])
+    h, w = xs_np[0].shape[2:]
+    flop = 2.0 * 9 * (cin * feature_size + 2 * num_layers * feature_size ** 2 + feature_size * cout) * h * w * n
     with torch.no_grad():
         xs = [torch.from_numpy(a[:n]) for a in xs_np]
-        forward(layers, xs, num_layers)                       # warm-up (oneDNN primitive creation)
+        forward(layers, xs, num_layers)                       # warm-up (oneDNN primitive creation, thread pool)
+        forward(layers, xs, num_layers)
         done, spent = 0, 0.0
-        while spent < budget_s and done < 10 * xs_np[0].shape[0]:
-            xs = [torch.from_numpy(a[:n]) for a in xs_np]
+        while spent < budget_s:
             t0 = time.perf_counter()
             y = forward(layers, xs, num_layers)
-            dt = time.perf_counter() - t0
-            spent += dt
-            done += xs[0].shape[0]
-            if dt < 2.0 and n * 2 <= xs_np[0].shape[0]:
-                n *= 2
-    return done / spent, done, cores, y.numpy()
+            spent += time.perf_counter() - t0
+            done += n
+    return done / spent, done, cores, y.numpy(), flop * (done / n) / spent / 1e9

@@ -1,0 +1,197 @@
+"""dsen2_amd.cli on the CPU: band labelling, ROI rounding, and the import-guarded GDAL branch against an in-memory
+stand-in for `osgeo.gdal` (GDAL itself is not installed in the build image).  The network is replaced by a stand-in
+(nearest-neighbour up-sampling) — what is tested is the flow of testing/s2_tiles_supres.py around it."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+DESC10 = ['B4, central wavelength 665 nm', 'B3, central wavelength 560 nm', 'B2, central wavelength 490 nm',
+          'B8, central wavelength 842 nm']
+DESC20 = ['B5, central wavelength 705 nm', 'B6, central wavelength 740 nm', 'B7, central wavelength 783 nm',
+          'B8A, central wavelength 865 nm', 'B11, central wavelength 1610 nm', 'B12, central wavelength 2190 nm']
+DESC60 = ['B1, central wavelength 443 nm', 'B9, central wavelength 945 nm', 'B10, central wavelength 1375 nm']
+
+
+@pytest.fixture
+def fake_supres(monkeypatch):
+    from dsen2_amd import supres
+
+    def up(lo, k):
+        return np.repeat(np.repeat(np.asarray(lo, np.float32), k, axis=0), k, axis=1)
+    monkeypatch.setattr(supres, 'DSen2_20', lambda d10, d20, deep=False: up(d20, 2))
+    monkeypatch.setattr(supres, 'DSen2_60', lambda d10, d20, d60, deep=False: up(d60, 6))
+    return supres
+
+
+def _arrays(n=48):
+    rng = np.random.default_rng(0)
+    d10 = rng.integers(1, 9000, size=(n, n, 4)).astype(np.uint16)
+    d20 = rng.integers(1, 9000, size=(n // 2, n // 2, 6)).astype(np.uint16)
+    d60 = rng.integers(1, 9000, size=(n // 6, n // 6, 3)).astype(np.uint16)
+    return d10, d20, d60
+
+
+def test_copy_original_bands_labels_follow_the_channel_order(fake_supres, tmp_path):
+    """The 10 m channels are labelled in the SAFE sub-dataset order B4,B3,B2,B8 by default and by --bands10 / a
+    `bands10` entry otherwise: channel i always ends up under ITS name."""
+    from dsen2_amd import cli
+    d10, d20, d60 = _arrays()
+    inp = str(tmp_path / 'tile.npz')
+    np.savez(inp, data10=d10, data20=d20, data60=d60[:, :, :2])
+    out = str(tmp_path / 'o1.npz')
+    assert cli.main([inp, out, '--copy_original_bands']) == 0
+    bands = np.load(out, allow_pickle=True)['bands'].item()
+    assert list(bands)[:4] == ['B4', 'B3', 'B2', 'B8']
+    for i, name in enumerate(['B4', 'B3', 'B2', 'B8']):
+        assert np.array_equal(bands[name], d10[:, :, i])
+    out = str(tmp_path / 'o2.npz')
+    assert cli.main([inp, out, '--copy_original_bands', '--bands10', 'B2,B3,B4,B8', '--run_60']) == 0
+    bands = np.load(out, allow_pickle=True)['bands'].item()
+    assert list(bands) == ['B2', 'B3', 'B4', 'B8', 'SRB5', 'SRB6', 'SRB7', 'SRB8A', 'SRB11', 'SRB12', 'SRB1', 'SRB9']
+    assert np.array_equal(bands['B2'], d10[:, :, 0]) and np.array_equal(bands['B4'], d10[:, :, 2])
+    assert np.array_equal(bands['SRB9'], np.repeat(np.repeat(d60[:, :, 1].astype(np.float32), 6, 0), 6, 1))
+    np.savez(inp, data10=d10, data20=d20, bands10=np.array(['B8', 'B2', 'B3', 'B4']))
+    out = str(tmp_path / 'o3.npz')
+    assert cli.main([inp, out, '--copy_original_bands']) == 0
+    bands = np.load(out, allow_pickle=True)['bands'].item()
+    assert np.array_equal(bands['B8'], d10[:, :, 0]) and np.array_equal(bands['B4'], d10[:, :, 3])
+    with pytest.raises(ValueError):
+        cli.main([inp, out, '--copy_original_bands', '--bands10', 'B2,B3'])
+
+
+def test_roi_is_snapped_to_60m_pixels():
+    from dsen2_amd import cli
+    assert cli.snap_roi(5, 7, 250, 245, 264, 264) == (0, 6, 245, 245)          # s2_tiles_supres.py:111-120
+    assert cli.snap_roi(250, 245, 5, 7, 264, 264) == (0, 6, 245, 245)          # point order does not matter
+    assert cli.snap_roi(-10, -10, 10000, 10000, 120, 60) == (0, 0, 119, 59)
+    assert cli.short_band_name('B8A, central wavelength 865 nm') == 'B8A'
+    assert cli.tidy_description('B4, central wavelength 665 nm', 'GTiff') == 'B4 (665 nm)'
+    assert cli.tidy_description('a, b', 'ENVI') == 'a b'
+
+
+# ---- an in-memory stand-in for osgeo.gdal: just what s2_tiles_supres.py (and cli.GdalProduct) touch ----
+class _Band(object):
+    def __init__(self, ds, i):
+        self.ds, self.i = ds, i
+
+    def GetDescription(self):
+        return self.ds.desc[self.i]
+
+    def SetDescription(self, d):
+        self.ds.desc[self.i] = d
+
+    def WriteArray(self, a):
+        self.ds.data[self.i] = np.array(a, dtype=np.float64)
+
+
+class _Dataset(object):
+    def __init__(self, data=None, desc=None, subs=None):
+        self.data, self.desc, self.subs = data, desc, subs or []
+        self.geot, self.proj, self.flushed = (600000.0, 10.0, 0.0, 5000000.0, 0.0, -10.0), 'PROJCS["UTM 33N"]', False
+
+    RasterCount = property(lambda self: len(self.data))
+    RasterXSize = property(lambda self: self.data[0].shape[1])
+    RasterYSize = property(lambda self: self.data[0].shape[0])
+
+    def GetSubDatasets(self):
+        return self.subs
+
+    def GetRasterBand(self, i):
+        return _Band(self, i - 1)
+
+    def ReadAsArray(self, xoff, yoff, xsize, ysize, buf_xsize, buf_ysize):
+        return np.stack([b[yoff:yoff + ysize, xoff:xoff + xsize] for b in self.data])
+
+    def GetGeoTransform(self):
+        return self.geot
+
+    def SetGeoTransform(self, g):
+        self.geot = tuple(g)
+
+    def GetProjection(self):
+        return self.proj
+
+    def SetProjection(self, p):
+        self.proj = p
+
+    def FlushCache(self):
+        self.flushed = True
+
+
+def _fake_gdal(d10, d20, d60, can_create=True):
+    gdal = types.ModuleType('osgeo.gdal')
+    store = {'SUB10': _Dataset([d10[:, :, i] for i in range(4)], list(DESC10)),
+             'SUB20': _Dataset([d20[:, :, i] for i in range(6)], list(DESC20)),
+             'SUB60': _Dataset([d60[:, :, i] for i in range(3)], list(DESC60))}
+    store['S2A.zip'] = _Dataset(subs=[('SUB10', 'Bands B2, B3, B4, B8 with 10m resolution, UTM 33N'),
+                                      ('SUB20', 'Bands B5, ... with 20m resolution, UTM 33N'),
+                                      ('SUB60', 'Bands B1, B9, B10 with 60m resolution, UTM 33N'),
+                                      ('SUBTCI', 'True color image, UTM 33N')])
+    created = {}
+
+    class Driver(object):
+        def GetMetadata(self):
+            return {gdal.DCAP_CREATE: 'YES'} if can_create else {}
+
+        def Create(self, path, w, h, n, dtype):
+            created[path] = _Dataset([np.zeros((h, w)) for _ in range(n)], [''] * n)
+            return created[path]
+    gdal.DCAP_CREATE, gdal.GDT_Float64 = 'DCAP_CREATE', 7
+    gdal.Open = lambda name: store.get(os.path.basename(name))
+    gdal.GetDriverByName = lambda fmt: Driver() if fmt in ('GTiff', 'ENVI', 'PCIDSK') else None
+    gdal.created = created
+    return gdal
+
+
+@pytest.fixture
+def with_gdal(monkeypatch):
+    def install(d10, d20, d60, **kw):
+        gdal = _fake_gdal(d10, d20, d60, **kw)
+        osgeo = types.ModuleType('osgeo')
+        osgeo.gdal = gdal
+        monkeypatch.setitem(sys.modules, 'osgeo', osgeo)
+        monkeypatch.setitem(sys.modules, 'osgeo.gdal', gdal)
+        return gdal
+    return install
+
+
+def test_gdal_branch_reads_selects_and_writes_like_the_reference(fake_supres, with_gdal, tmp_path, capsys):
+    """s2_tiles_supres.py:102-329 (sub-datasets, band selection by name, ROI, ReadAsArray -> HWC) and :371-413
+    (GTiff writer, geo-transform moved to the ROI, descriptions)."""
+    from dsen2_amd import cli
+    d10, d20, d60 = _arrays(48)
+    gdal = with_gdal(d10, d20, d60)
+    out = str(tmp_path / 'sr.tif')
+    assert cli.main(['S2A.zip', out, '--run_60', '--copy_original_bands', '--roi_x_y', '13,7,40,30']) == 0
+    printed = capsys.readouterr().out
+    assert 'Selected pixel region: xmin=12, ymin=6, xmax=35, ymax=29' in printed
+    ds = gdal.created[out]
+    assert ds.flushed and ds.RasterCount == 12 and ds.data[0].shape == (24, 24)
+    assert ds.desc == ['B4 (665 nm)', 'B3 (560 nm)', 'B2 (490 nm)', 'B8 (842 nm)', 'SRB5 (705 nm)', 'SRB6 (740 nm)',
+                       'SRB7 (783 nm)', 'SRB8A (865 nm)', 'SRB11 (1610 nm)', 'SRB12 (2190 nm)', 'SRB1 (443 nm)', 'SRB9 (945 nm)']
+    assert np.array_equal(ds.data[0], d10[6:30, 12:36, 0])                                  # original B4, ROI applied
+    assert np.array_equal(ds.data[4], np.repeat(np.repeat(d20[3:15, 6:18, 0], 2, 0), 2, 1))    # SRB5 from the stand-in
+    assert np.array_equal(ds.data[11], np.repeat(np.repeat(d60[1:5, 2:6, 1], 6, 0), 6, 1))     # B10 is never selected
+    assert ds.geot == (600000.0 + 120, 10.0, 0.0, 5000000.0 - 60, 0.0, -10.0) and ds.proj == 'PROJCS["UTM 33N"]'
+    # without --run_60 the 60 m sub-dataset is not read and only the 20 m bands are written
+    out2 = str(tmp_path / 'sr20.tif')
+    assert cli.main(['S2A.zip', out2]) == 0
+    assert gdal.created[out2].RasterCount == 6 and gdal.created[out2].data[0].shape == (48, 48)
+
+
+def test_gdal_branch_falls_back_to_npz_and_without_gdal_says_so(fake_supres, with_gdal, tmp_path, capsys, monkeypatch):
+    from dsen2_amd import cli
+    d10, d20, d60 = _arrays(24)
+    with_gdal(d10, d20, d60, can_create=False)
+    out = str(tmp_path / 'sr.dat')
+    assert cli.main(['S2A.zip', out, '--output_file_format', 'GTiff']) == 0            # s2_tiles_supres.py:350-360
+    printed = capsys.readouterr().out
+    assert "Gdal doesn't support creating GTiff files" in printed and 'Writing to npz as a fallback' in printed
+    bands = np.load(out + '.npz', allow_pickle=True)['bands'].item()
+    assert list(bands) == ['SRB5 (705 nm)', 'SRB6 (740 nm)', 'SRB7 (783 nm)', 'SRB8A (865 nm)', 'SRB11 (1610 nm)', 'SRB12 (2190 nm)']
+    monkeypatch.setitem(sys.modules, 'osgeo', None)                                     # import osgeo -> ImportError
+    assert cli.main(['S2A.zip', out]) == 2
+    assert 'GDAL (osgeo) is not importable' in capsys.readouterr().out

@@ -154,3 +154,18 @@ def test_cli_npz_round_trip(model_dir, tmp_path, golden_dir):
     quiet(cli.main, [inp, out2, '--roi_x_y', '5,7,250,245', '--models', supres.MDL_PATH])
     b2 = np.load(out2, allow_pickle=True)['bands'].item()
     assert b2['SRB5'].shape == (240, 246)
+
+
+def test_demo_script_prints_a_parity_rmse():
+    """demo.py (the counterpart of testing/demoDSen2.py:14-35): runs DSen2_60 + DSen2_20 on the committed T33UUB crop
+    with seeded random-init weights and prints the reference's `RMSE: %.4f` line against the float64 oracle pipeline."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'demo.py')], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    m = re.search(r'^RMSE: (\d+\.\d{4})$', p.stdout, re.M)
+    assert m, p.stdout[-1500:]
+    assert float(m.group(1)) / 2000 < 1e-4                      # raw reflectance units -> normalised domain
+    assert 'Super-resolving the 60m data into 10m bands' in p.stdout and 'sr20 (264, 264, 6) float32' in p.stdout

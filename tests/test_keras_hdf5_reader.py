@@ -1,6 +1,8 @@
-"""weights._from_keras_hdf5 against a synthetic file laid out like a keras 2.x full-model checkpoint
-(training/supres_train.py:195-201: ModelCheckpoint(save_weights_only=False) -> /model_weights/<layer>/<layer>/...).
-Needs h5py, which the system python of the build image lacks (skipped there; run under /opt/conda/bin/python3.9)."""
+"""weights._from_keras_hdf5 and cli._load (.mat) against synthetic files laid out like a keras 2.x full-model
+checkpoint (training/supres_train.py:195-201: ModelCheckpoint(save_weights_only=False) ->
+/model_weights/<layer>/<layer>/...) and like the reference's MATLAB v7.3 tiles (testing/demoDSen2.py:14-28).
+Needs h5py, which the system python of the build image lacks: there tests/test_h5py_suite.py runs this file under
+/opt/conda/bin/python3.9 (which has h5py but no torch — nothing here may import torch)."""
 import os
 import sys
 
@@ -11,7 +13,7 @@ h5py = pytest.importorskip('h5py')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def write_keras_like(path, cin, cout, d, f, flat):
+def write_keras_like(path, cin, cout, d, f, flat, first_index=1, shuffle_names=False, bias_first=False):
     from dsen2_amd import weights as W
     shapes = W.layer_shapes(cin, cout, d, f)
     names, off = [], 0
@@ -26,10 +28,12 @@ def write_keras_like(path, cin, cout, d, f, flat):
                 sub.create_dataset('kernel:0', data=k)
                 sub.create_dataset('bias:0', data=b)
                 wn = [('%s/kernel:0' % name).encode(), ('%s/bias:0' % name).encode()]
+                if bias_first:
+                    wn.reverse()
             g.attrs['weight_names'] = wn
             names.append(name.encode())
         add('input_1'); add('input_2'); add('concatenate_1')
-        ci = 0
+        ci = first_index - 1
         for li, (a, o) in enumerate(shapes):
             k = flat[off:off + 9 * a * o].reshape(3, 3, a, o); off += 9 * a * o
             b = flat[off:off + o]; off += o
@@ -40,6 +44,8 @@ def write_keras_like(path, cin, cout, d, f, flat):
                 if li % 2 == 0:
                     add('add_%d' % ci)
         add('add_final')
+        if shuffle_names:
+            names = [names[i] for i in np.random.default_rng(0).permutation(len(names))]
         root.attrs['layer_names'] = names
 
 
@@ -52,3 +58,49 @@ def test_reader_round_trip(tmp_path):
     assert np.array_equal(got, flat)
     with pytest.raises(ValueError):
         W.load_flat(p, 12, 2, 6, 128)
+
+
+def test_reader_does_not_trust_attribute_or_weight_order(tmp_path):
+    """conv layers are ordered by the numeric suffix of their names (conv2d_37.. when other models were built in the
+    same keras session), kernel / bias are picked by name: a shuffled layer_names attribute, an offset numbering and
+    bias-before-kernel weight_names all read back the same flat vector."""
+    from dsen2_amd import weights as W
+    flat = W.random_he_uniform(12, 2, 6, 128, seed=4, bias_scale=0.1)
+    for kw in (dict(shuffle_names=True), dict(first_index=37), dict(bias_first=True),
+               dict(first_index=9, shuffle_names=True, bias_first=True)):
+        p = str(tmp_path / ('s2_030_%s.hdf5' % '_'.join(sorted(kw))))
+        write_keras_like(p, 12, 2, 6, 128, flat, **kw)
+        assert np.array_equal(W.load_flat(p, 12, 2, 6, 128), flat), kw
+
+
+def test_reader_rejects_a_layer_that_is_not_a_conv(tmp_path):
+    from dsen2_amd import weights as W
+    flat = W.random_he_uniform(10, 6, 1, 128, seed=5)
+    p = str(tmp_path / 'odd.hdf5')
+    write_keras_like(p, 10, 6, 1, 128, flat)
+    with h5py.File(p, 'a') as fh:
+        g = fh['model_weights'].create_group('batch_normalization_1')
+        g.attrs['weight_names'] = [b'batch_normalization_1/gamma:0', b'batch_normalization_1/beta:0']
+        names = [n if isinstance(n, bytes) else str(n).encode() for n in fh['model_weights'].attrs['layer_names']] + [b'batch_normalization_1']
+        fh['model_weights'].attrs['layer_names'] = names
+    with pytest.raises(ValueError):
+        W.load_flat(p, 10, 6, 1, 128)
+
+
+def test_cli_reads_matlab_v73_tiles(tmp_path):
+    """cli._load on a .mat laid out like data/S2A_MSIL1C_20170527_T33UUB.mat: MATLAB stores [x, y, c] column-major,
+    so h5py sees datasets [c, y, x]; readh5 (testing/demoDSen2.py:14-28) transposes them back to HWC."""
+    from dsen2_amd import cli
+    rng = np.random.default_rng(1)
+    im10 = rng.integers(0, 9000, size=(24, 18, 4)).astype(np.uint16)
+    im20 = rng.integers(0, 9000, size=(12, 9, 6)).astype(np.uint16)
+    im60 = rng.integers(0, 9000, size=(4, 3, 2)).astype(np.uint16)
+    p = str(tmp_path / 'tile.mat')
+    with h5py.File(p, 'w') as fh:
+        for k, a in (('im10', im10), ('im20', im20), ('im60', im60)):
+            fh.create_dataset(k, data=np.ascontiguousarray(a.transpose()))
+    d10, d20, d60 = cli._load(p)
+    assert np.array_equal(d10, im10) and np.array_equal(d20, im20) and np.array_equal(d60, im60)
+    with h5py.File(p, 'a') as fh:
+        del fh['im60']
+    assert cli._load(p)[2] is None
