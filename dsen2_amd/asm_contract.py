@@ -68,19 +68,21 @@ def check_listing(text, src):
     need(dma, 'no LDS-DMA instruction found')
     allowed = set()
     for i in dma:
-        need(code[i - 1] == 's_nop 0' and re.match(r's_mov_b32 m0, s\d+', code[i - 2]), 'DMA without its M0 write + wait state',
+        need(code[i - 1] == 's_nop 0' and re.match(r's_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$', code[i - 2]), 'DMA without its M0 write + wait state',
              code[i - 2:i + 1])
         allowed.update((i - 2,))
-        # the statement's save (before the first M0 write) and restore (after the last DMA)
-        j = i - 3
-        if re.match(r's_mov_b32 s\d+, m0', code[j]):
-            allowed.add(j)
+        # the statement's save (before the first M0 write; the EXEC-narrowing form has two more scalar moves in
+        # between) and restore (after the last DMA)
+        for j in range(i - 3, max(i - 7, -1), -1):
+            if re.match(r's_mov_b32 (s\d+|vcc_lo|vcc_hi), m0$', code[j]):
+                allowed.add(j)
+                break
         k = i + 1
-        if re.match(r's_mov_b32 m0, s\d+', code[k]):
+        if re.match(r's_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$', code[k]):
             allowed.add(k)
     for i in m0:
         need(i in allowed, 'M0 touched outside a DMA statement', code[max(0, i - 2):i + 3])
-    saves = sum(1 for ln in code if re.match(r's_mov_b32 s\d+, m0', ln))
+    saves = sum(1 for ln in code if re.match(r's_mov_b32 (s\d+|vcc_lo|vcc_hi), m0$', ln))
     need(saves > 0, 'the DMA statements no longer save M0')
     need(not any('scratch_' in ln for ln in code), 'a DMA kernel spills registers')
     need(not any(ln.startswith(('s_swappc', 's_call')) for ln in code), 'a DMA kernel calls a function (an epilogue was not inlined)')
@@ -102,7 +104,7 @@ def check_listing(text, src):
         expect = {0: (0, 32), 1: (64, 64), 3: (64, 64)}
         found = 0
         for name, body in _kernels(text).items():
-            m = re.search(r'conv3x3_body16w_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)
+            m = re.search(r'conv3x3_body16[wx]_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)
             if not m or int(m.group(4)) != 0:
                 continue
             found += 1
@@ -114,7 +116,7 @@ def check_listing(text, src):
             need(len(other) <= 1, 'unexpected vector-memory instructions in the bf16 body kernel', other[:4])
             need((loads, stores) == expect[int(m.group(3))],
                  'epilogue %s has %d loads / %d stores, the waits count %r' % (m.group(3), loads, stores, expect[int(m.group(3))]))
-        need(found >= 6, 'expected the 6 product instantiations of conv3x3_body16w_kernel, found %d' % found)
+        need(found >= 6, 'expected the 6 product instantiations of the bf16 body kernel, found %d' % found)
 
 
 def check_sources(hipcc, flags, verbose=False):

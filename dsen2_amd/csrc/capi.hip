@@ -220,6 +220,10 @@ int dsen2_model_workspace_bytes(const dsen2_model* m, int n, int h, int w, size_
   return DSEN2_OK;
 }
 
+static hipError_t launch_bf16_body(const ConvParams& p, int feat, int epilogue, const Tuning& t, hipStream_t stream) {
+  return launch_conv3x3_body16w(p, feat, epilogue, t.ablate, stream, t.grid_cap);
+}
+
 static int check_shape(const dsen2_model* m, int n, int h, int w) {
   if (n <= 0 || h <= 0 || w <= 0) return fail(DSEN2_ERR_INVALID, "bad shape n=%d h=%d w=%d", n, h, w);
   if ((size_t)h * w * (size_t)(m ? m->feat : 256) >= ((size_t)1 << 29))
@@ -279,13 +283,13 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
       const Layer& LA = m->layers[li++];
       ConvParams pa = make_params(reinterpret_cast<const float*>(hi), P + LA.w_off, P + LA.b_off, nullptr,
                                   reinterpret_cast<float*>(tbf), n, h, w, 0, 0.f);
-      HIP_TRY(launch_conv3x3_body16w(pa, m->feat, kEpiRelu, abl, stream));
+      HIP_TRY(launch_bf16_body(pa, m->feat, kEpiRelu, m->tune, stream));
       const Layer& LB = m->layers[li++];
       const bool last = i + 1 == m->num_layers;
       ConvParams pb = make_params(reinterpret_cast<const float*>(tbf), P + LB.w_off, P + LB.b_off,
                                   reinterpret_cast<const float*>(hi), last ? a : reinterpret_cast<float*>(hi), n, h, w, 0, 0.1f);
       pb.out2 = lo;
-      HIP_TRY(launch_conv3x3_body16w(pb, m->feat, last ? kEpiResidualF32 : kEpiResidual, abl, stream));
+      HIP_TRY(launch_bf16_body(pb, m->feat, last ? kEpiResidualF32 : kEpiResidual, m->tune, stream));
     }
   } else {
     if (ev_body0) HIP_TRY(hipEventRecord(ev_body0, stream));
@@ -417,7 +421,7 @@ int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, c
                                reinterpret_cast<const float*>(dev + wn * 2), reinterpret_cast<const float*>(dev_res_hi),
                                reinterpret_cast<float*>(epilogue == kEpiResidual ? dev_res_hi : dev_out), n, h, w, 0, res_scale);
     p.out2 = dev_res_lo;
-    e = launch_conv3x3_body16w(p, feat, epilogue, default_tuning().ablate, stream);
+    e = launch_bf16_body(p, feat, epilogue, default_tuning(), stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFree(dev);
@@ -451,7 +455,7 @@ int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, c
   p.diag = g_diag_stamps;
 #endif
   auto launch = [&]() -> hipError_t {
-    return L.bf16 ? launch_conv3x3_body16w(p, m->feat, epi, abl, stream, m->tune.grid_cap) : launch_conv3x3(p, L.geom, L.epilogue, abl, stream);
+    return L.bf16 ? launch_bf16_body(p, m->feat, epi, m->tune, stream) : launch_conv3x3(p, L.geom, L.epilogue, abl, stream);
   };
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
