@@ -188,9 +188,10 @@ def main():
         flops = pix * FLOP_PER_PIXEL_BODY
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, 'profiles', 'body_conv_traffic.json')
-        if os.path.exists(tj) and args.config == 'dsen2_20_fp32' and args.batch == BATCH:
-            tdat = json.load(open(tj))      # PMC counters cannot be read in-process: committed profile of this config
-            traffic, traffic_src = tdat['traffic_bytes'], tdat['source']
+        if os.path.exists(tj) and args.batch == BATCH:
+            tdat = json.load(open(tj)).get(args.config)     # PMC counters cannot be read in-process: committed profile of this config
+            if tdat:
+                traffic, traffic_src = tdat['traffic_bytes'], tdat['source']
         achieved = flops / (ms * 1e-3) / 1e12
         result['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK,
                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK, 4), 'traffic': traffic,

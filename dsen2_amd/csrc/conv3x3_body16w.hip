@@ -220,7 +220,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   auto stamp = [&](int k) __attribute__((always_inline)) {
     if constexpr ((ABL & 32) != 0) {
       if (p.diag && lid < 4 && (wave == 0 || wave == 7) && lane == 0)
-        p.diag[(((size_t)lid * 2 + (wave == 7)) * 16 + (stamp_it & 15)) * 32 + k] = __builtin_amdgcn_s_memtime();
+        p.diag[(((size_t)lid * 2 + (wave == 7)) * 16 + (stamp_it & 15)) * 32 + k] =
+            k == 19 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();      // slot 19: the 100 MHz counter
     }
   };
 
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   for (int it = 0; it <= my_items; ++it) {
     stamp_it = it;
     stamp(0);
+    stamp(19);
     epilogue(it > 0 ? lid + (it - 1) * G : lid, it > 0);
     __builtin_amdgcn_sched_barrier(0);
     stamp(1);

@@ -41,8 +41,33 @@ def cpu_model_name():
     return 'unknown'
 
 
+def cgroup_cpu_limit():
+    """CPUs this process may use according to its cgroup's CPU quota (v2 cpu.max, v1 cfs quota); None if unlimited."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            return max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            return max(1, int(q / float(per) + 0.5))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def physical_cores():
-    """Physical cores available to this process (SMT siblings counted once, cgroup/affinity limits respected)."""
+    """Physical cores available to this process: SMT siblings counted once, affinity mask and cgroup CPU quota
+    respected (a container limited to 16 CPUs of a 128-core host must not run 128 oneDNN threads)."""
+    n = _physical_cores_affinity()
+    lim = cgroup_cpu_limit()
+    return min(n, lim) if lim else n
+
+
+def _physical_cores_affinity():
     try:
         import os
         avail = os.sched_getaffinity(0)

@@ -37,7 +37,13 @@ names = {0: 'loop top', 14: 'residual loads issued', 15: 'pass 0 done', 16: 'pas
          9: 'step 6', 10: 'step 7', 11: 'step 8', 12: 'end of chunk 1', 13: 'end of item',
          31: 'chunk 2 tap 0 end', 19: 'tap1 DMAs issued', 20: 'tap1 MFMAs issued', 21: 'tap1 own DMA wait', 22: 'tap1 barrier',
          30: 'tap 2 end', 23: 'tap3 DMAs issued', 24: 'tap3 MFMAs issued', 25: 'tap3 own DMA wait', 26: 'tap3 barrier'}
-order = [0, 14, 15, 16, 17, 18, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 31, 19, 20, 21, 22, 30, 23, 24, 25, 26, 13]
+order = [0, 14, 15, 16, 17, 18, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13]
+# in-kernel clock: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime) between the loop tops of items 1 and 3
+for wg in (0, 1):
+    c = st[wg, 0]
+    if c[3, 19] > c[1, 19]:
+        print('workgroup %d: in-kernel clock %.3f GHz (items 1..3: %d cycles in %d ticks of 10 ns)' % (
+            wg, (c[3, 0] - c[1, 0]) / (c[3, 19] - c[1, 19]) * 0.1, c[3, 0] - c[1, 0], c[3, 19] - c[1, 19]))
 for wg in (0, 1):
     for wv in (0, 1):
         print('workgroup %d wave %d: cycles since the item loop top of item 0 (100 MHz s_memtime ticks x clock ratio)' % (wg, 7 * wv))
