@@ -55,7 +55,11 @@ struct ConvCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int CIN, int KC, int COUT, int NT, int EPI, int NWAVES, int WAVES_PER_SIMD>
+// CREAL (first layer only, CIN = KC = 16): number of real input channels (10 or 12; 0 = all CIN).  The padding
+// channels are zeros in both operands; skipping their MFMAs leaves every accumulator's fma chain — and so every
+// output bit — unchanged: channels 8.. are paired (8,9), (10,11) in one MFMA each, the same order in which the
+// padded form adds them between its zero terms.
+template <int CIN, int KC, int COUT, int NT, int EPI, int NWAVES, int WAVES_PER_SIMD, int CREAL = 0>
 __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kernel(const ConvParams p) {
   using C = ConvCfg<CIN, KC, NT, NWAVES>;
   constexpr int kThreads = C::THREADS;
@@ -179,6 +183,26 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
       const float* const ap = wb + a_lane;
 #pragma unroll
       for (int s = 0; s < KC / 8; ++s) {
+        if constexpr (CREAL > 0) {
+          static_assert(CREAL % 2 == 0 && CREAL > 8 && CREAL <= 16 && KC == 16 && CIN == 16, "first-layer form");
+          if (s == 1) {
+            // channels 8 .. CREAL-1: lanes 0-31 supply channel 8 + 2m, lanes 32-63 channel 9 + 2m (both from k-group 2)
+#pragma unroll
+            for (int m = 0; m < (CREAL - 8) / 2; ++m) {
+              float a1[C::MB], b1[C::PB];
+#pragma unroll
+              for (int mb = 0; mb < C::MB; ++mb) a1[mb] = ap[(2 * NT + mb * 32) * 4 - hsel * NT * 4 + 2 * m + hsel];
+#pragma unroll
+              for (int pb = 0; pb < C::PB; ++pb) b1[pb] = bp[pb * 2 * kHalo * C::PSTR + 8 - 4 * hsel + 2 * m + hsel];
+#pragma unroll
+              for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+                for (int pb = 0; pb < C::PB; ++pb)
+                  acc[mb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mb], b1[pb], acc[mb][pb], 0, 0, 0);
+            }
+            continue;
+          }
+        }
         f32x4 a[C::MB], b[C::PB];
 #pragma unroll
         for (int mb = 0; mb < C::MB; ++mb) a[mb] = *reinterpret_cast<const f32x4*>(ap + (2 * s * NT + mb * 32) * 4);
@@ -246,10 +270,10 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
   }
 }
 
-template <int CIN, int KC, int COUT, int NT, int EPI, int NWAVES = 8, int WAVES_PER_SIMD = 2>
+template <int CIN, int KC, int COUT, int NT, int EPI, int NWAVES = 8, int WAVES_PER_SIMD = 2, int CREAL = 0>
 static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
   using C = ConvCfg<CIN, KC, NT, NWAVES>;
-  auto kern = conv3x3_mfma_kernel<CIN, KC, COUT, NT, EPI, NWAVES, WAVES_PER_SIMD>;
+  auto kern = conv3x3_mfma_kernel<CIN, KC, COUT, NT, EPI, NWAVES, WAVES_PER_SIMD, CREAL>;
   static bool attr_set[64] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -276,7 +300,12 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, const Tuning& tune, Pac
     return true;
   }
   if (cout != 128 && cout != 256) return false;
-  if (cin <= 16) { *g = PackGeom{16, 128, 16, cout, 0}; return true; }
+  if (cin <= 16) {
+    // first layer: variant = number of real channels whose MFMAs are issued (10 / 12: the Sentinel-2 band groups;
+    // 0 = all 16 padded channels, the reference structure)
+    *g = PackGeom{16, 128, 16, cout, (tune.body_variant != 0 && (cin == 10 || cin == 12)) ? cin : 0};
+    return true;
+  }
   if (cin == cout) {
     // every structure of the F->F body convolution reads the same packing (KC = 32, NT = 128):
     // 11-14 = conv3x3_body32.hip sub-variants 0-3 (14 = default); 0 = one tile per workgroup (this file)
@@ -334,6 +363,14 @@ hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogu
   if (geom.variant >= 11 && geom.variant <= 14 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)
     return launch_conv3x3_body32(p, cin_pad, epilogue, geom.variant - 11, ablate, stream);
   if (ablate != 0) return hipErrorInvalidValue;
+  if (cin_pad == 16 && epilogue == kEpiRelu && (geom.variant == 10 || geom.variant == 12)) {
+    if (cout_pad == 128)
+      return geom.variant == 10 ? launch_one<16, 16, 128, 128, kEpiRelu, 8, 2, 10>(p, stream)
+                                : launch_one<16, 16, 128, 128, kEpiRelu, 8, 2, 12>(p, stream);
+    if (cout_pad == 256)
+      return geom.variant == 10 ? launch_one<16, 16, 256, 128, kEpiRelu, 8, 2, 10>(p, stream)
+                                : launch_one<16, 16, 256, 128, kEpiRelu, 8, 2, 12>(p, stream);
+  }
 #define DSEN2_CASE(CI, KC_, CO, NT_, EP) \
   if (cin_pad == CI && cout_pad == CO && epilogue == EP) return launch_one<CI, KC_, CO, NT_, EP>(p, stream);
   DSEN2_CASE(16, 16, 128, 128, kEpiRelu)

@@ -129,3 +129,26 @@ def test_forward_timed_runs_the_same_forward():
     ms = m.time_body_in_forward(dev, out=y1, iters=3)
     assert torch.equal(y0, y1)
     assert 0.0 < ms < 50.0
+
+
+@pytest.mark.parametrize('bands,feat', [((4, 6), 128), ((4, 6, 2), 128), ((4, 6), 256)])
+def test_first_layer_without_padding_mfmas_gives_the_same_bits(bands, feat):
+    """The model's first convolution issues MFMAs for its 10 / 12 real input channels only; the single-layer entry
+    point on the SAME data zero-padded to 16 channels runs the generic kernel with all 16.  Skipping zero terms must
+    not change one bit (ragged image; a d=0 network = first convolution + output convolution)."""
+    from dsen2_amd.DSen2Net import conv3x3_nhwc, s2model
+    cin, cout = sum(bands), bands[-1]
+    flat = do.he_uniform_weights(cin, cout, 0, feat, seed=8, bias_scale=0.05)
+    xs = do.synthetic_inputs(3, 21, 37, bands, seed=8)
+    m = s2model(tuple((b, None, None) for b in bands), num_layers=0, feature_size=feat)
+    m.set_weights_flat(flat)
+    dev = [torch.from_numpy(a).cuda() for a in xs]
+    y = m.forward_device(dev)
+    (k0, b0), (k1, b1) = do.split_weights(flat, cin, cout, 0, feat)
+    x16 = torch.zeros((3, 21, 37, 16), device='cuda')
+    x16[..., :cin] = torch.cat(dev, dim=1).permute(0, 2, 3, 1)
+    k16 = np.zeros((3, 3, 16, feat), np.float32)
+    k16[:, :, :cin] = k0
+    a = conv3x3_nhwc(x16, k16, b0, epilogue=0)
+    y_ref = conv3x3_nhwc(a, k1, b1, epilogue=2, aux=dev[-1])
+    assert torch.equal(y, y_ref)
