@@ -86,7 +86,8 @@ const char* dsen2_last_error(void) { return g_err; }
 #ifdef DSEN2_DIAG
 // Diagnostic build only — not declared in include/dsen2_hip.h.  key 0: structure of the fp32 body convolution
 // (14 default, 11-13 sub-variants of conv3x3_body32.hip, 0 one tile per workgroup); key 1: timing-only ablation
-// mask of the persistent body kernels (outputs are WRONG while non-zero); key 2: output-layer kernel (1 / 0).
+// mask of the persistent body kernels (outputs are WRONG while non-zero); key 2: output-layer kernel (2 = vector units,
+// 0 = padded MFMA block).
 int dsen2_diag_set(int key, int value) {
   if (key == 0) {
     if (value != 0 && (value < 11 || value > 14)) return fail(DSEN2_ERR_INVALID, "body variant %d unknown", value);
@@ -98,7 +99,7 @@ int dsen2_diag_set(int key, int value) {
     return DSEN2_OK;
   }
   if (key == 2) {
-    if (value != 0 && value != 1) return fail(DSEN2_ERR_INVALID, "output variant %d unknown", value);
+    if (value != 0 && value != 2) return fail(DSEN2_ERR_INVALID, "output variant %d unknown", value);
     g_diag_tuning.out_variant = value;
     return DSEN2_OK;
   }

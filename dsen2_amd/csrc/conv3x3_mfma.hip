@@ -295,7 +295,7 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, const Tuning& tune, Pac
   if (cin <= 0 || cout <= 0) return false;
   if (epilogue == kEpiSkipNCHW) {
     if (cout > 32 || (cin != 128 && cin != 256)) return false;
-    if (cout <= 16 && tune.out_variant == 1) { *g = PackGeom{16, 16, cin, 16, 7}; return true; }   // conv3x3_out.hip
+    if (cout <= 8 && tune.out_variant == 2) { *g = PackGeom{16, 8, cin, 8, 8}; return true; }      // conv3x3_out.hip, vector units
     *g = PackGeom{32, 32, cin, 32, 0};
     return true;
   }
@@ -318,6 +318,10 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, const Tuning& tune, Pac
 size_t packed_weight_floats(const PackGeom& g) { return (size_t)9 * g.cin_pad * g.cout_pad; }
 
 void pack_conv_weights_host(const float* k, int cin, int cout, const PackGeom& g, float* dst) {
+  if (g.variant == 8) {          // the vector-unit output kernel has its own operand order
+    pack_out_valu_weights_host(k, cin, cout, dst);
+    return;
+  }
   const int ncc = g.cin_pad / g.kc, nslab = g.cout_pad / g.nt, ng = g.kc / 4;
   size_t i = 0;
   for (int slab = 0; slab < nslab; ++slab)
@@ -357,7 +361,7 @@ void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch
 
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, int ablate, hipStream_t stream) {
   const int cin_pad = geom.cin_pad, cout_pad = geom.cout_pad;
-  if (geom.variant == 7 && epilogue == kEpiSkipNCHW) return launch_conv3x3_out(p, cin_pad, stream);
+  if (geom.variant == 8 && epilogue == kEpiSkipNCHW) return launch_conv3x3_out_valu(p, cin_pad, stream);
   // 11-14: the DMA-fed kernel (conv3x3_body32.hip) and its sub-variants.  An image it cannot address (>= 2 GiB of
   // activations) is an error, not a silent switch of kernels: dsen2's entry points reject such shapes up front.
   if (geom.variant >= 11 && geom.variant <= 14 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)

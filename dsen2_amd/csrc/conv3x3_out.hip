@@ -1,50 +1,45 @@
 // conv3x3_out.hip — the network's last convolution: F -> Cout (6 or 2 channels) 3x3 'same' + bias + the
-// low-resolution skip input, NHWC in, NCHW out (utils/DSen2Net.py:35,38,41).
+// low-resolution skip input, NHWC in, NCHW out (utils/DSen2Net.py:35,38,41) — on the VECTOR units.
 //
-// With only 6 (or 2) output channels a 32-wide MFMA block would be 81 % (94 %) padding, so this kernel uses
-// v_mfma_f32_16x16x4_f32 (exact f32, 32 cycles): M = 16 pixels (one tile row), N = 16 output channels (Cout
-// zero-padded), k = 4.  A lane fetches 4 consecutive input channels with one ds_read_b128 and feeds 4 MFMAs;
-// MFMA j of a 16-channel step contracts channels {16s + 4q + j : q = lane>>4} on both operands.
-// D[px][o] puts output channel o on lane&15 and 4 consecutive pixels in a lane's 4 registers, which is exactly
-// 16 contiguous bytes of an NCHW row: the epilogue is one float4 load (skip) and one float4 store per block.
-//
-// One workgroup = 8 waves = one 16x16 tile; wave w owns tile rows 2w and 2w+1.  LDS: halo tile of 16 channels
-// (double buffered) + the 9 taps x 16 channels x 16 outputs of the current channel chunk (double buffered);
-// one barrier per 16-channel chunk (72 MFMAs per wave); two workgroups per CU.
+// With 6 (or 2) output channels a matrix-core tile is mostly padding: a 32-wide MFMA block 81 % (94 %), the
+// 16x16x4 form (round 1's kernel: 171 us at the bench config) still 62 %.  The f32 vector rate equals the f32
+// matrix rate on gfx950 (157.3 TFLOP/s) and a vector kernel pads nothing: 122 us, same bits.
 #include "dsen2_internal.h"
 
 namespace dsen2 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-namespace outk {
-constexpr int KC = 16;                         // 16-channel chunks: 70 KB of LDS = two workgroups per CU, one's chunk hand-over
-                                               // under the other's MFMAs (32-channel chunks, one workgroup per CU: 205 -> 171 us)
-constexpr int NO = 16;                         // padded output channels
+// Cout <= 8 (more output channels fall back to the padded 32-wide MFMA block of conv3x3_mfma.hip).  One thread = one pixel x
+// half of the output channels (wave parity h: outputs h, h+2, h+4, ..): NSLOT accumulators, v_fma_f32 with the
+// weight as the instruction's scalar operand.  Weights are re-packed [chunk][tap][h][16 chain positions][4 slots]
+// so that one s_load_dwordx4 per chain position feeds NSLOT FMAs; the chain order (channel 4q + j at position
+// 4j + q of a 16-channel chunk) is the k order of round 1's v_mfma_f32_16x16x4_f32 kernel (an f32 MFMA is an fma
+// chain over its k), so the results are the same bits (checked against the round-1 library on whole networks).
+// Input: 18x18 halo tile of 16 channels, double buffered through registers; 51.8 KB of LDS, two workgroups per CU.
+namespace outv {
+constexpr int KC = 16;
 constexpr int THREADS = 512;
 constexpr int PSTR = KC + 4;
 constexpr int IN_FLOATS = kHaloPix * PSTR;
-constexpr int WCH = 9 * KC * NO;               // floats per channel chunk of weights (all 9 taps)
 constexpr int IN_PIECES = kHaloPix * (KC / 4);
 constexpr int IN_ROUNDS = (IN_PIECES + THREADS - 1) / THREADS;
-constexpr int W_PIECES = WCH / 4;
-constexpr int W_ROUNDS = (W_PIECES + THREADS - 1) / THREADS;
-constexpr size_t LDS_BYTES = (size_t)(2 * IN_FLOATS + 2 * WCH) * sizeof(float);   // 70,272 B
-}  // namespace outk
+constexpr size_t LDS_BYTES = (size_t)(2 * IN_FLOATS) * sizeof(float);     // 51,840 B
+constexpr int WCHUNK = 9 * 2 * 16 * 4;                                    // floats per 16-channel chunk of weights
+}  // namespace outv
 
-template <int CIN>
-__global__ __launch_bounds__(outk::THREADS, 2) void conv3x3_out_kernel(const ConvParams p) {
-  using namespace outk;
+template <int CIN, int NSLOT>
+__global__ __launch_bounds__(outv::THREADS, 2) void conv3x3_out_valu_kernel(const ConvParams p) {
+  using namespace outv;
   constexpr int NCC = CIN / KC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const in_s = smem;                    // [2][324][PSTR]
-  float* const w_s = smem + 2 * IN_FLOATS;     // [2][9][KC/4][NO][4]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15;
-  const int q = lane >> 4;
+  const int h = wave & 1;                      // which half of the output channels
+  const int row = 4 * (wave >> 1) + (lane >> 4), col = lane & 15;
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -78,100 +73,94 @@ __global__ __launch_bounds__(outk::THREADS, 2) void conv3x3_out_kernel(const Con
     for (int e = 0; e < 4; ++e) v[e] = g_off[r] >= 0 ? t[e] : 0.f;
     if (s_off[r] >= 0) *reinterpret_cast<f32x4*>(buf + s_off[r]) = v;
   };
-  auto load_w = [&](int r, int cc) -> f32x4 {
-    const int piece = r * THREADS + tid;
-    return *reinterpret_cast<const f32x4*>(p.wpk + (size_t)cc * WCH + (piece < W_PIECES ? piece : 0) * 4);
-  };
-  auto store_w = [&](float* buf, int r, f32x4 v) {
-    const int piece = r * THREADS + tid;
-    if (piece < W_PIECES) *reinterpret_cast<f32x4*>(buf + piece * 4) = v;
-  };
 
-  // operand addresses: A = pixels (row 2*wave + mb of the tile, column l15), channels 16s + 4q .. +3
-  //                    B = weights [tap][g = 4s + q][o = l15][4]
-  const int x_lane = ((2 * wave) * kHalo + l15) * PSTR + 4 * q;
-  const int w_lane = (q * NO + l15) * 4;
+  const int x_lane = (row * kHalo + col) * PSTR;
+  const float* const wv = p.wpk + h * 64;        // [chunk][tap][h][16][4]: wave-uniform -> scalar loads
 
-  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float acc[NSLOT];
+#pragma unroll
+  for (int m = 0; m < NSLOT; ++m) acc[m] = 0.f;
 
   {
-    f32x4 ir[IN_ROUNDS], wr[W_ROUNDS];
+    f32x4 ir[IN_ROUNDS];
 #pragma unroll
     for (int r = 0; r < IN_ROUNDS; ++r) ir[r] = load_in(r, 0);
 #pragma unroll
-    for (int r = 0; r < W_ROUNDS; ++r) wr[r] = load_w(r, 0);
-#pragma unroll
     for (int r = 0; r < IN_ROUNDS; ++r) store_in(in_s, r, ir[r]);
-#pragma unroll
-    for (int r = 0; r < W_ROUNDS; ++r) store_w(w_s, r, wr[r]);
   }
   __syncthreads();
 
 #pragma unroll 1
   for (int cc = 0; cc < NCC; ++cc) {
     const float* const ib = in_s + (cc & 1) * IN_FLOATS;
-    const float* const wb = w_s + (cc & 1) * WCH;
     float* const ib_next = in_s + ((cc + 1) & 1) * IN_FLOATS;
-    float* const wb_next = w_s + ((cc + 1) & 1) * WCH;
-    const int ncc = cc + 1 < NCC ? cc + 1 : cc;       // last chunk re-fetches itself into the unused buffers
-    f32x4 ir[IN_ROUNDS], wr[W_ROUNDS];
+    const int ncc = cc + 1 < NCC ? cc + 1 : cc;       // last chunk re-fetches itself into the unused buffer
+    f32x4 ir[IN_ROUNDS];
 #pragma unroll
     for (int r = 0; r < IN_ROUNDS; ++r) ir[r] = load_in(r, ncc);
+    const float* const wc = wv + (size_t)cc * WCHUNK;
+    // 18 half taps of 8 chain positions: the 32 weights of half tap k+1 are fetched (two s_load_dwordx16) while half
+    // tap k's FMAs run.  The scheduling barriers keep hipcc from hoisting a whole chunk's 576 scalars at once, which
+    // it then has to park in VGPR lanes (v_writelane / v_readlane per weight).
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    // constant address space + wave-uniform address = scalar loads (s_load_dwordx16) into SGPRs, whatever else the
+    // optimiser believes about aliasing
+    typedef const __attribute__((address_space(4))) f32x16* const_f32x16_ptr;
+    auto load_half = [&](int k, f32x16& a, f32x16& b) __attribute__((always_inline)) {
+      const float* const wh = wc + (k >> 1) * 128 + (k & 1) * 32;
+      a = *reinterpret_cast<const_f32x16_ptr>(reinterpret_cast<size_t>(wh));
+      b = *reinterpret_cast<const_f32x16_ptr>(reinterpret_cast<size_t>(wh + 16));
+    };
+    f32x16 wa[2], wb[2];
+    load_half(0, wa[0], wb[0]);
+    f32x4 x[4];
 #pragma unroll
-    for (int r = 0; r < W_ROUNDS; ++r) wr[r] = load_w(r, ncc);
-
+    for (int k = 0; k < 18; ++k) {
+      const int tap = k >> 1;
+      if ((k & 1) == 0) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const float* const xp = ib + x_lane + (dy * kHalo + dx) * PSTR;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap - dy * 3;
-#pragma unroll
-      for (int s = 0; s < KC / 16; ++s) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(wb + w_lane + ((tap * (KC / 4) + 4 * s) * NO) * 4);
-        f32x4 a[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-          a[mb] = *reinterpret_cast<const f32x4*>(ib + x_lane + ((mb + dy) * kHalo + dx) * PSTR + 16 * s);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][j], b[j], acc[mb], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(xp + 4 * q);
       }
+      // (waiting for this half tap's operands BEFORE issuing the next fetches — so that they fly under the FMAs —
+      // measured slower: 139 vs 122 us; four waves per SIMD already cover the scalar-load latency)
+      if (k + 1 < 18) load_half(k + 1, wa[(k + 1) & 1], wb[(k + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ii = 0; ii < 8; ++ii) {             // chain position i = 4j + q  <->  channel 4q + j
+        const int i = 8 * (k & 1) + ii;
+        const int q = i & 3, j = i >> 2;
+        const f32x16& wsrc = ii < 4 ? wa[k & 1] : wb[k & 1];
+#pragma unroll
+        for (int m = 0; m < NSLOT; ++m) acc[m] = __builtin_fmaf(x[q][j], wsrc[4 * (ii & 3) + m], acc[m]);
+      }
+      // pin the half tap's FMAs here (without this the optimiser sinks every FMA below all scalar loads)
+#pragma unroll
+      for (int m = 0; m < NSLOT; ++m) asm volatile("" : "+v"(acc[m]));
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < IN_ROUNDS; ++r) store_in(ib_next, r, ir[r]);
-#pragma unroll
-    for (int r = 0; r < W_ROUNDS; ++r) store_w(wb_next, r, wr[r]);
     __syncthreads();
   }
 
-  // epilogue: D[px][o]: lane owns channel o = l15 and pixels 4q .. 4q+3 of tile row 2*wave + mb
-  const int o = l15;
-  if (o < p.cout_real) {
-    const float bias = p.bias[o];
-    const int x = tx0 + 4 * q;
+  const int y = ty0 + row, xg = tx0 + col;
+  if (y < p.h && xg < p.w) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      const int y = ty0 + 2 * wave + mb;
-      if (y < p.h && x < p.w) {
-        const size_t idx = ((size_t)img * p.cout_real + o) * img_pix + (size_t)y * p.w + x;
-        if (x + 4 <= p.w && (p.w & 3) == 0) {
-          const f32x4 sk = *reinterpret_cast<const f32x4*>(p.aux + idx);
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (acc[mb][e] + bias) + sk[e];
-          *reinterpret_cast<f32x4*>(p.out + idx) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (x + e < p.w) p.out[idx + e] = (acc[mb][e] + bias) + p.aux[idx + e];
-        }
+    for (int m = 0; m < NSLOT; ++m) {
+      const int o = 2 * m + h;
+      if (o < p.cout_real) {
+        const size_t idx = ((size_t)img * p.cout_real + o) * img_pix + (size_t)y * p.w + xg;
+        p.out[idx] = (acc[m] + p.bias[o]) + p.aux[idx];
       }
     }
   }
 }
 
-template <int CIN>
-static hipError_t launch_out_one(const ConvParams& p, hipStream_t stream) {
-  auto kern = conv3x3_out_kernel<CIN>;
+template <int CIN, int NSLOT>
+static hipError_t launch_out_valu_one(const ConvParams& p, hipStream_t stream) {
+  auto kern = conv3x3_out_valu_kernel<CIN, NSLOT>;
   static bool attr_set[64] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -179,21 +168,39 @@ static hipError_t launch_out_one(const ConvParams& p, hipStream_t stream) {
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!attr_set[dev]) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)outk::LDS_BYTES);
+                            (int)outv::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
   const long long tiles = (long long)p.n * p.tiles_x * p.tiles_y;
   if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(outk::THREADS), outk::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(outv::THREADS), outv::LDS_BYTES, stream, p);
   return hipGetLastError();
 }
 
-hipError_t launch_conv3x3_out(const ConvParams& p, int feat, hipStream_t stream) {
-  if (p.cout_real < 1 || p.cout_real > outk::NO) return hipErrorInvalidValue;
-  if (feat == 128) return launch_out_one<128>(p, stream);
-  if (feat == 256) return launch_out_one<256>(p, stream);
+// weights packed by pack_out_valu_weights_host (PackGeom variant 8)
+hipError_t launch_conv3x3_out_valu(const ConvParams& p, int feat, hipStream_t stream) {
+  if (p.cout_real < 1 || p.cout_real > 8) return hipErrorInvalidValue;
+  const int nslot = (p.cout_real + 1) / 2;
+#define DSEN2_OUTV(F, S) if (feat == F && nslot == S) return launch_out_valu_one<F, S>(p, stream);
+  DSEN2_OUTV(128, 1) DSEN2_OUTV(128, 2) DSEN2_OUTV(128, 3) DSEN2_OUTV(128, 4)
+  DSEN2_OUTV(256, 1) DSEN2_OUTV(256, 2) DSEN2_OUTV(256, 3) DSEN2_OUTV(256, 4)
+#undef DSEN2_OUTV
   return hipErrorInvalidValue;
+}
+
+// kernel HWIO (3,3,cin,cout<=8) -> [chunk of 16 ch][tap][h][chain position i = 4j + q][slot m]:
+//   value = K[tap][16*chunk + 4q + j][2m + h]   (0 where 2m + h >= cout);  9*cin*8 floats
+void pack_out_valu_weights_host(const float* k, int cin, int cout, float* dst) {
+  size_t n = 0;
+  for (int cc = 0; cc < cin / 16; ++cc)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 16; ++i)
+          for (int m = 0; m < 4; ++m, ++n) {
+            const int c = 16 * cc + 4 * (i & 3) + (i >> 2), o = 2 * m + h;
+            dst[n] = o < cout ? k[((size_t)tap * cin + c) * cout + o] : 0.f;
+          }
 }
 
 }  // namespace dsen2

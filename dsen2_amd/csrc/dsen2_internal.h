@@ -46,7 +46,8 @@ struct ConvParams {
 struct Tuning {
   int body_variant = 14;   // fp32 F->F body convolution: 11-14 = conv3x3_body32.hip sub-variants 0-3; 0 = one tile per
                            // workgroup (conv3x3_mfma.hip, the independent first implementation)
-  int out_variant = 1;     // last layer: 1 = 16x16x4 kernel (conv3x3_out.hip); 0 = padded 32-wide block (conv3x3_mfma.hip)
+  int out_variant = 2;     // last layer: 2 = vector-unit kernel for Cout <= 8 (conv3x3_out.hip; falls back to 0 above 8),
+                           // 0 = padded 32-wide MFMA block (conv3x3_mfma.hip, the reference structure)
   int ablate = 0;          // timing-only ablation mask of the persistent body kernels (DSEN2_DIAG builds; wrong outputs)
   int grid_cap = 0;        // DSEN2_DIAG builds: launch at most this many workgroups of the bf16 body kernel (0 = one per CU)
 };
@@ -54,8 +55,10 @@ struct Tuning {
 // Supported (CIN_PAD, COUT_PAD, epilogue) combinations; returns hipErrorInvalidValue otherwise.
 struct PackGeom { int kc, nt, cin_pad, cout_pad, variant; };
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, int ablate, hipStream_t stream);
-// last layer, F -> Cout<=16, 16x16x4 MFMA (conv3x3_out.hip); weights packed with KC=16, NT=16
-hipError_t launch_conv3x3_out(const ConvParams& p, int feat, hipStream_t stream);
+// last layer, F -> Cout <= 8, on the vector units (conv3x3_out.hip; PackGeom variant 8, weights packed by
+// pack_out_valu_weights_host)
+hipError_t launch_conv3x3_out_valu(const ConvParams& p, int feat, hipStream_t stream);
+void pack_out_valu_weights_host(const float* kernel_hwio, int cin, int cout, float* dst);
 // DMA-fed fp32 kernel (conv3x3_body32.hip): F = 128 or 256, images < 2 GiB; weights packed with KC=32, NT=128
 bool body32_supports(const ConvParams& p, int cout);
 hipError_t launch_conv3x3_body32(const ConvParams& p, int feat, int epilogue, int sub, int ablate, hipStream_t stream);
