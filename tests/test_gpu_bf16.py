@@ -128,3 +128,26 @@ def test_bf16_network_ragged():
         ref = c_oracle.forward(xs, flat, 3, 256)
         scale = float(np.sqrt(np.mean(ref ** 2)))
         assert do.rmse(m.predict(xs), ref) / scale < 5e-3, (n, h, w)
+
+
+def test_bf16_zero_weights_return_skip_input_exactly_and_full_batch_f128():
+    """Size-independent properties of the bf16 path at DSen2 width: all-zero parameters make the network the identity
+    on its low-resolution input (the residual planes carry the first convolution's zeros exactly), and a full batch
+    of 512 patches is deterministic and permutation-equivariant."""
+    from dsen2_amd.DSen2Net import s2model
+    xs = do.synthetic_inputs(3, 32, 32, (4, 6, 2), seed=4)
+    m = s2model(((4, None, None), (6, None, None), (2, None, None)), num_layers=6, feature_size=128, precision='bf16')
+    m.set_weights_flat(np.zeros(do.num_params(12, 2, 6, 128), np.float32))
+    assert np.array_equal(m.predict(xs), xs[2])
+    flat = do.he_uniform_weights(10, 6, 6, 128, seed=1, bias_scale=0.05)
+    xs = do.synthetic_inputs(512, 32, 32, (4, 6), seed=0)
+    m = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128, precision='bf16')
+    m.set_weights_flat(flat)
+    dev = [torch.from_numpy(a).cuda() for a in xs]
+    y1 = m.forward_device(dev).clone()
+    assert torch.equal(m.forward_device(dev), y1)
+    perm = torch.randperm(512, generator=torch.Generator().manual_seed(3)).cuda()
+    assert torch.equal(m.forward_device([d[perm].contiguous() for d in dev]), y1[perm])
+    idx = [0, 255, 511]
+    ref = c_oracle.forward([a[idx] for a in xs], flat, 6, 128)
+    assert do.rmse(y1.cpu().numpy()[idx], ref) / float(np.sqrt(np.mean(ref ** 2))) < 5e-3

@@ -169,3 +169,62 @@ def test_demo_script_prints_a_parity_rmse():
     assert m, p.stdout[-1500:]
     assert float(m.group(1)) / 2000 < 1e-4                      # raw reflectance units -> normalised domain
     assert 'Super-resolving the 60m data into 10m bands' in p.stdout and 'sr20 (264, 264, 6) float32' in p.stdout
+
+
+BF16_GATE_REL = 1e-2        # rmse / signal rms in the normalised domain (tests/test_gpu_vdsen2_bf16.py)
+
+
+def test_dsen2_20_and_60_in_bf16_through_the_drop_in_surface(model_dir, monkeypatch):
+    """supres.PRECISION = 'bf16' (DSEN2_PRECISION / --precision): the same DSen2_20 / DSen2_60 calls with bf16
+    operands on the residual-block convolutions, against the float64 oracle pipeline on real tile geometry
+    (128 / 192-pixel patches, non-dividing sizes, clamped last tiles)."""
+    from dsen2_amd import supres
+    monkeypatch.setattr(supres, 'PRECISION', 'bf16')
+    supres.clear_model_cache()
+    rng = np.random.default_rng(4)
+    d10 = rng.integers(35, 6000, size=(240, 150, 4)).astype(np.float32)
+    d20 = rng.integers(35, 6000, size=(120, 75, 6)).astype(np.float32)
+    out, _ = quiet(supres.DSen2_20, d10, d20, deep=False)
+    ref = oracle_dsen2_20(d10, d20, model_dir['s2_032_lr_1e-04'])
+    rel = do.rmse(out, ref) / float(np.sqrt(np.mean(ref ** 2)))
+    print('DSen2_20 bf16: rmse / signal rms = %.3e' % rel)
+    assert out.shape == (240, 150, 6) and out.dtype == np.float32 and rel < BF16_GATE_REL
+    monkeypatch.setattr(supres, 'PRECISION', 'fp32')
+    supres.clear_model_cache()
+    out32, _ = quiet(supres.DSen2_20, d10, d20, deep=False)
+    assert do.rmse(out32, ref) / 2000 < RMSE_GATE_NORMALISED                  # and the switch really switches
+    assert not np.array_equal(out, out32)
+    monkeypatch.setattr(supres, 'PRECISION', 'bf16')
+    supres.clear_model_cache()
+    d10 = rng.integers(35, 6000, size=(216, 180, 4)).astype(np.float32)
+    d20 = rng.integers(35, 6000, size=(108, 90, 6)).astype(np.float32)
+    d60 = rng.integers(35, 6000, size=(36, 30, 2)).astype(np.float32)
+    out, _ = quiet(supres.DSen2_60, d10, d20, d60, deep=False)
+    p = po.get_test_patches60(d10, d20, d60, patchSize=192, border=12, f32_coords=True)
+    p = [a / np.float32(2000) for a in p]
+    used = int(np.ceil(216 / 168.0) * np.ceil(180 / 168.0))
+    pred = np.zeros((p[0].shape[0], 2, 192, 192))
+    pred[:used] = c_oracle.forward([a[:used] for a in p], model_dir['s2_030_lr_1e-05'], 6, 128)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = po.recompose_images(pred, border=12, size=d10.shape).astype(np.float64) * 2000
+    rel = do.rmse(out, ref) / float(np.sqrt(np.mean(ref ** 2)))
+    print('DSen2_60 bf16: rmse / signal rms = %.3e' % rel)
+    assert out.shape == (216, 180, 2) and rel < BF16_GATE_REL
+
+
+def test_predict_deep_in_bf16(tmp_path, monkeypatch):
+    """deep=True with PRECISION = 'bf16': BASELINE configs[4]'s network through `_predict` (testing/supres.py:53-66)."""
+    from dsen2_amd import supres
+    flat = do.he_uniform_weights(10, 6, 32, 256, seed=13, bias_scale=0.02)
+    np.save(str(tmp_path / 's2_033_lr_1e-04.npy'), flat)
+    monkeypatch.setattr(supres, 'MDL_PATH', str(tmp_path) + os.sep)
+    monkeypatch.setattr(supres, 'PRECISION', 'bf16')
+    supres.clear_model_cache()
+    xs = do.synthetic_inputs(2, 16, 16, (4, 6), seed=22)
+    out, printed = quiet(supres._predict, xs, ((4, None, None), (6, None, None)), True)
+    assert 's2_033_lr_1e-04.hdf5' in printed and out.shape == (2, 6, 16, 16) and out.dtype == np.float32
+    ref = c_oracle.forward(xs, flat, 32, 256)
+    rel = do.rmse(out, ref) / float(np.sqrt(np.mean(ref ** 2)))
+    print('VDSen2 bf16 through _predict: rmse / signal rms = %.3e' % rel)
+    assert rel < BF16_GATE_REL
+    supres.clear_model_cache()
