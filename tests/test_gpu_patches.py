@@ -133,3 +133,27 @@ def test_integer_rasters_are_widened_on_device(golden_dir):
         want = ref if cast(d10).dtype != np.int16 else gp.get_test_patches(a10.astype(np.float32), a20.astype(np.float32),
                                                                             patchSize=32, border=4)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.parametrize('size,patch,border', [(10980, 128, 8), (10980, 192, 12), (1000, 128, 8)])
+def test_full_tile_gather_then_recompose_is_the_identity(size, patch, border):
+    """BASELINE configs[3] at its real size (a 10980^2 Sentinel-2 tile: 9801 patches of 128, 4356 of 192): tiling the
+    10 m image with get_test_patches' geometry and recomposing the patches' inner crops must return the image bit
+    for bit — every pixel comes back from exactly the patch recompose_images reads it from (patches.py:374-405),
+    whatever the clamped last row / column of tiles overlaps."""
+    import torch
+    from dsen2_amd import patches as P
+    dev = P.default_device()
+    g = torch.Generator(device='cpu').manual_seed(size + patch)
+    # two bands keep the round trip within a few GB at full size; values as Sentinel-2 digital numbers
+    img = torch.randint(35, 13110, (size, size, 2), generator=g, dtype=torch.int32).to(torch.float32).to(dev)
+    lr = patch // 2                      # tile on the 20 m grid like DSen2_20 (crop origins x 2)
+    org, n_alloc = P.tile_origins((size // 2, size // 2), lr, border // 2)
+    assert org.shape[0] == int(np.ceil(size / float(patch - 2 * border))) ** 2
+    pats = P.gather_patches_device(img, org, 2, border, patch, n_alloc, first=0, count=org.shape[0])
+    back = P.recompose_device(pats, border, (size, size))
+    assert torch.equal(back, img)
+    # and the gather-to-root form: inner crops recomposed with border 0 (dsen2_amd/supres.py, multi-GPU path)
+    crops = pats[:, :, border:patch - border, border:patch - border].contiguous()
+    del pats
+    assert torch.equal(P.recompose_device(crops, 0, (size, size)), img)
