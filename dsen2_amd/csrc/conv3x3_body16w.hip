@@ -50,7 +50,8 @@ constexpr int WCH_BYTES = 32 * 128 * 2;     // one weight chunk: [4 k-groups][12
 constexpr int RING = 8;                     // weight ring slots
 constexpr int LEAD = RING - 1;              // chunk c + LEAD is issued in step c
 constexpr int THREADS = 512;                // 8 waves: (channel half) x (4-row strip)
-constexpr int MB = 4, PB = 8;               // per wave: 4 x 16 channels, 8 x 16 pixels (4 rows x 2 column halves)
+constexpr int MB = 4, PB = 8;               // per wave: 4 x 16 channels, 8 x 16 pixels (8 rows of one 16-column half)
+constexpr int XR = PB + 2;                  // halo-row fragments kept per dx
 constexpr size_t LDS_BYTES = (size_t)2 * IN_BYTES + (size_t)RING * WCH_BYTES + 256 * 4;
 // Cache policy of the once-per-block residual traffic (hi and lo loads, lo stores): nt (aux bit 1).  The stream is as
 // large as the Infinity Cache and each value is touched once per block; same-box A/B on the VDSen2 bf16 bench:
@@ -67,12 +68,21 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int W_PER_STEP = 2;               // weight pieces an issuing wave moves per step (its own and +4)
 constexpr int rounds_in_tap(int t) { return t < 5 ? 2 : 0; }
 constexpr int first_round_of_tap(int t) { return 2 * t; }
-// vector-memory operations an issuing wave issues AFTER the weight DMAs of step s-5 up to the end of step s (tap t):
-// the weight DMAs of steps s-4..s and those steps' input rounds (issued before the step's weight DMAs).
-// vmcnt(N) at the end of step s therefore retires the wave's pieces of weight chunk s+2 and everything older.
-constexpr int younger_ops(int t, bool has_w, bool has_in) {
+// BARRIERS.  The workgroup synchronises after taps 1, 3, 5, 7 and 8 of every chunk — five barriers per nine steps, not
+// nine (each one drains the matrix pipe of both waves of a SIMD).  What a barrier after tap t must publish is every
+// weight chunk read before the next barrier: fragments of chunk s+1 are read DURING step s, so the barrier after
+// step s = tap t covers chunks up to s + wait_depth(t) (3, or 2 after tap 7 because tap 8 has its own barrier).
+// Ring reuse stays safe with LEAD = 7: the DMA issued at the start of step s overwrites chunk s-1, whose fragments
+// were read during step s-2, and between any step s-2 and step s lies a barrier of that pattern.
+constexpr bool barrier_after(int t) { return t == 8 || (t & 1) != 0; }
+constexpr int wait_depth(int t) { return t == 7 ? 2 : 3; }
+// vector-memory operations an issuing wave issues AFTER the weight DMAs of step s+depth-LEAD up to the end of step s
+// (tap t): the weight DMAs of the LEAD-depth steps up to s and those steps' input rounds (issued before the step's
+// weight DMAs).  vmcnt(N) at the end of step s therefore retires the wave's pieces of weight chunk s+depth and
+// everything older.
+constexpr int younger_ops(int t, int depth, bool has_w, bool has_in) {
   int n = 0;
-  for (int j = 0; j < 5; ++j) n += (has_w ? W_PER_STEP : 0) + (has_in ? rounds_in_tap((t - j + 9) % 9) : 0);
+  for (int j = 0; j < LEAD - depth; ++j) n += (has_w ? W_PER_STEP : 0) + (has_in ? rounds_in_tap((t - j + 9) % 9) : 0);
   return n;
 }
 // the input chunk staged in taps 0-4 is first read during tap 8: by the end of tap 7 everything up to tap 4's last
@@ -105,7 +115,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1;                 // 64-channel half of the slab
-  const int wp = wave >> 1;                // rows 4*wp .. 4*wp+3 of the tile
+  const int wp = wave >> 1;                // pixel quarter of the tile: 8 rows x 16 columns
+  const int wrow = 8 * (wp >> 1), wcol = 16 * (wp & 1);
   const int l15 = lane & 15;
   const int q4 = lane >> 4;
 
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   // ---- per-lane operand addresses (bytes) ----
   // B operand (pixels): lane -> pixel column l15 of a 16-pixel row segment, channel group q4 of the chunk
   // A operand (weights): [k-group q4][row = wn*64 + 16*mb + l15][16 B]
-  const int x_lane = (q4 * QS + (4 * wp) * HW + l15) * 16;
+  const int x_lane = (q4 * QS + wrow * HW + wcol + l15) * 16;
   const int w_lane = (q4 * 128 + wn * 64 + l15) * 16;
 
   // ---- prologue: first item's input chunk 0, weight chunks 0 .. LEAD-1 ----
@@ -201,13 +212,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   wait_vmcnt<0>();
   __syncthreads();
 
-  f32x4 w_cur[MB], x_cur[PB];
+  // Pixel fragments: XR = PB + 2 halo-row segments (rows wrow + 0..9 of the staged tile, 16 columns from wcol + dx)
+  // serve the three taps dy = 0..2 of one dx: MFMA (mb, pb) of tap (dy, dx) multiplies x_row[pb + dy].
+  f32x4 w_cur[MB], x_row[XR];
   int mf_slot = 0;
-  auto read_x = [&](f32x4 (&xf)[PB], const char* ib, int tap) {
-    const int dy = tap / 3, dx = tap - dy * 3;
-    const char* xp_ = ib + x_lane + (dy * HW + dx) * 16;
+  auto read_rows = [&](const char* ib) {                    // dx = 0 of a chunk
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) xf[pb] = *reinterpret_cast<const f32x4*>(xp_ + ((pb >> 1) * HW + 16 * (pb & 1)) * 16);
+    for (int r = 0; r < XR; ++r) x_row[r] = *reinterpret_cast<const f32x4*>(ib + x_lane + r * HW * 16);
   };
   auto read_w1 = [&](int mb, const char* wb) -> f32x4 {
     return *reinterpret_cast<const f32x4*>(wb + w_lane + mb * 256);
@@ -225,12 +236,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
     }
   };
 
-  // ---- epilogue of one item: lane = pixel (row 4*wp + (pb>>1), column 16*(pb&1) + l15), group (pr, pb) =
+  // ---- epilogue of one item: lane = pixel (row wrow + pb, column wcol + l15), group (pr, pb) =
   // 8 consecutive channels slab*128 + wn*64 + 32*pr + 8*q4 held by accumulators 2*pr and 2*pr+1 ----
   auto epilogue = [&](int item, bool valid) __attribute__((always_inline)) {
     const Tile t = tile_of(item);
     const int ch8 = t.slab * 128 + wn * 64 + 8 * q4;
-    const int ex = t.tx0 + l15, ey = t.ty0 + 4 * wp;
+    const int ex = t.tx0 + wcol + l15, ey = t.ty0 + wrow;
     // Byte offset of group (pr, pb) inside its image, branch-free.  16-bit tensors are BLOCKED: 8-channel block k of
     // an image is a plane [h][w] of 16-byte pixels, so the 16 lanes of a pixel-row segment touch 256 contiguous
     // bytes and the texture addresser coalesces them four lanes at a time (with channels-last pixels 512 B apart it
@@ -241,14 +252,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
     const unsigned base_pix = (unsigned)(ey * p.w + ex);
     const unsigned bad_all = valid ? 0u : 0x80000000u;
     auto bad_of = [&](int pb) -> unsigned {
-      const int row = ey + (pb >> 1), col = ex + 16 * (pb & 1);
+      const int row = ey + pb, col = ex;
       return bad_all | (row < p.h ? 0u : 0x80000000u) | (col < p.w ? 0u : 0x80000000u);
     };
     auto plane_off = [&](int pr, int pb) -> unsigned {                // 16-bit blocked tensors
-      return (((blk0 + 4u * pr) * (unsigned)img_pix + base_pix + (unsigned)((pb >> 1) * p.w + 16 * (pb & 1))) * 16u & 0x7fffffffu) | bad_of(pb);
+      return (((blk0 + 4u * pr) * (unsigned)img_pix + base_pix + (unsigned)(pb * p.w)) * 16u & 0x7fffffffu) | bad_of(pb);
     };
     auto nhwc_f32_off = [&](int pr, int pb) -> unsigned {             // fp32 channels-last tensor (kEpiResidualF32)
-      return (((base_pix + (unsigned)((pb >> 1) * p.w + 16 * (pb & 1))) * (unsigned)COUT + (unsigned)(ch8 + 32 * pr)) * 4u & 0x7fffffffu) | bad_of(pb);
+      return (((base_pix + (unsigned)(pb * p.w)) * (unsigned)COUT + (unsigned)(ch8 + 32 * pr)) * 4u & 0x7fffffffu) | bad_of(pb);
     };
     const size_t img_elems = img_pix * COUT;
     if constexpr (EPI == kEpiRelu) {
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
       const auto f32_rsrc = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<char*>(p.out) + (EPI == kEpiResidualF32 ? (size_t)t.img * img_elems * 4 : 0), 0,
           EPI == kEpiResidualF32 ? (unsigned)(img_elems * 4) : 0, 0x00020000);
-      // pass j = tile row 4*wp + j: 4 groups (2 column halves x 2 channel pairs).  Residual loads run two passes
+      // pass j = rows wrow + 2j, 2j+1: 4 groups (2 rows x 2 channel pairs).  Residual loads run two passes
       // ahead of the stores in issue order (L0 L1 | C0 L2 S0 | C1 L3 S1 | C2 S2 | C3 S3): only the last pass's
       // loads are younger than a store (pass 0's), so vmcnt's in-order retirement exposes one store drain, not four
       u32x4 rh[4][4], rl[4][4];
@@ -391,8 +402,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
       const char* const wb = w_s + mf_slot * WCH_BYTES;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) w_cur[mb] = read_w1(mb, wb);
-      read_x(x_cur, in_s, 0);
+      read_rows(in_s);
     }
+    // These reads of chunk 0 happen IN the item's first step, not one step earlier like every other fragment read,
+    // and step 1's weight DMA reuses chunk 0's ring slot with no barrier after tap 0: synchronise here, once per item.
+    if constexpr (!(ABL & 16)) __syncthreads();
     stamp(2);
 
     // ONE copy of the nine-step body for every input chunk (a separate copy for the item's first chunk makes the
@@ -416,22 +430,32 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
           for (int r = 0; r < rounds_in_tap(tap); ++r) issue_in((cc + 1) & 1, first_round_of_tap(tap) + r, in_cc);
         }
         if constexpr (ISSUER && kW) issue_w();
-        // Fragments of the NEXT step are read into the registers of this one as soon as their last MFMA has
-        // issued: pixel fragment pb after the last channel block's MFMA on it, weight fragment mb after its 8 MFMAs —
-        // no second register set.  (An item's last step reads the next item's first fragments too; they are read
-        // again after the epilogue, which needs the registers.)
-        const char* const xb_nx = (tap < 8 ? ib : ib_next) + x_lane + ((tap < 8 ? (tap + 1) / 3 : 0) * HW + (tap < 8 ? (tap + 1) % 3 : 0)) * 16;
+        // Step s of a chunk computes tap (dy, dx) = (s % 3, s / 3): dx-major, so that the XR row fragments of one dx
+        // serve three steps (22 fragment reads per three steps instead of 36).  Fragments are refilled in place as
+        // soon as their last MFMA of this dx has issued: row 0 after (MB-1, 0) of dy = 0, row 1 after (MB-1, 0) of
+        // dy = 1, row pb + 2 after (MB-1, pb) of dy = 2; weight fragment mb after its 8 MFMAs.  The last dx of a chunk
+        // refills from the NEXT chunk's buffer, which is only complete after step 7's barrier: its rows 0 and 1 are
+        // read at the start of step 8.  (An item's last step reads the next item's first fragments too; they are
+        // read again after the epilogue, which needs the registers.)
+        constexpr int dy = tap % 3, dx = tap / 3;
+        const char* const xb_nx = (dx < 2 ? ib + (dx + 1) * 16 : ib_next) + x_lane;
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (tap == 8) {
+          x_row[0] = *reinterpret_cast<const f32x4*>(xb_nx);
+          x_row[1] = *reinterpret_cast<const f32x4*>(xb_nx + HW * 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
           for (int pb = 0; pb < PB; ++pb) {
             acc[mb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w_cur[mb]),
-                                                                  __builtin_bit_cast(bf16x8, x_cur[pb]),
+                                                                  __builtin_bit_cast(bf16x8, x_row[pb + dy]),
                                                                   acc[mb][pb], 0, 0, 0);
-            if (mb == MB - 1) {
+            if (mb == MB - 1 && (dy == 2 || (pb == 0 && dx < 2))) {
+              const int r = dy == 2 ? pb + 2 : dy;
               __builtin_amdgcn_sched_barrier(0);
-              x_cur[pb] = *reinterpret_cast<const f32x4*>(xb_nx + ((pb >> 1) * HW + 16 * (pb & 1)) * 16);
+              x_row[r] = *reinterpret_cast<const f32x4*>(xb_nx + r * HW * 16);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -441,25 +465,28 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
         }
         mf_slot = nx_slot;
         __builtin_amdgcn_sched_barrier(0);
-        // ISSUER: retire this wave's pieces of the weight chunk two steps ahead (issued five steps ago) and everything
-        // older; in an item's first five steps the previous epilogue's loads and stores are younger than that chunk
-        // and stay in flight.  Workers have no DMA of their own to wait for.
-        if constexpr (ISSUER) {
-          constexpr int kN0 = younger_ops(tap, kW, kIn);
-          constexpr int kN = (tap == 7 && kIn && younger_than_input(kW) < kN0) ? younger_than_input(kW) : kN0;
-          constexpr int kNE = kN + E_OPS < 63 ? kN + E_OPS : 63;
-          if constexpr (tap < 5 && kNE != kN) {
-            // vmcnt(kNE) in the item's first chunk, vmcnt(kN) otherwise.  The scalar branch lives inside ONE asm
-            // statement so that the nine-step body stays a single basic block (split into blocks, hipcc's register
-            // allocator shuffles the accumulators between them and spills into the DMA-counted vmcnt stream).
-            asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Ldsen2_w%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Ldsen2_e%=\n"
-                         ".Ldsen2_w%=:\n\ts_waitcnt vmcnt(%2)\n.Ldsen2_e%=:"
-                         ::"s"(cc), "n"(kN), "n"(kNE) : "memory", "scc");
-          } else {
-            wait_vmcnt<kN>();
+        // ISSUER, before a barrier: retire this wave's pieces of the weight chunk wait_depth steps ahead and everything
+        // older; while that chunk was issued before the previous epilogue (the item's first steps), the epilogue's
+        // loads and stores are younger than it and stay in flight.  Workers have no DMA of their own to wait for.
+        if constexpr (barrier_after(tap)) {
+          if constexpr (ISSUER) {
+            constexpr int kD = wait_depth(tap);
+            constexpr int kN0 = younger_ops(tap, kD, kW, kIn);
+            constexpr int kN = (tap == 7 && kIn && younger_than_input(kW) < kN0) ? younger_than_input(kW) : kN0;
+            constexpr int kNE = kN + E_OPS < 63 ? kN + E_OPS : 63;
+            if constexpr (tap + kD < LEAD && kNE != kN) {
+              // vmcnt(kNE) in the item's first chunk, vmcnt(kN) otherwise.  The scalar branch lives inside ONE asm
+              // statement so that the nine-step body stays a single basic block (split into blocks, hipcc's register
+              // allocator shuffles the accumulators between them and spills into the DMA-counted vmcnt stream).
+              asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Ldsen2_w%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Ldsen2_e%=\n"
+                           ".Ldsen2_w%=:\n\ts_waitcnt vmcnt(%2)\n.Ldsen2_e%=:"
+                           ::"s"(cc), "n"(kN), "n"(kNE) : "memory", "scc");
+            } else {
+              wait_vmcnt<kN>();
+            }
           }
+          if constexpr (!(ABL & 16)) __syncthreads();
         }
-        if constexpr (!(ABL & 16)) __syncthreads();
         if constexpr ((ABL & 32) != 0) {
           if (cc == 0) stamp(3 + tap);
           if (tap == 8 && cc == 1) stamp(12);

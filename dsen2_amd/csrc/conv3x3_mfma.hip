@@ -344,12 +344,15 @@ static inline uint16_t f32_to_bf16_rne(float f) {
 }
 
 void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch, bool perm16, uint16_t* dst) {
-  // [slab][cc (chunk_ch channels)][tap][g (8 channels)][o (128)][j (8)]: one (slab, cc, tap) chunk is the LDS image
+  // [slab][cc (chunk_ch channels)][step][g (8 channels)][o (128)][j (8)]: one (slab, cc, step) chunk is the LDS image.
+  // perm16 (conv3x3_body16w.hip's format): step s carries tap (dy, dx) = (s % 3, s / 3) — the kernel walks the taps
+  // dx-major to keep its pixel-row fragments over the three dy of one dx; otherwise step = tap.
   const int ncc = cin / chunk_ch, nslab = cout / 128, ng = chunk_ch / 8;
   size_t i = 0;
   for (int slab = 0; slab < nslab; ++slab)
     for (int cc = 0; cc < ncc; ++cc)
-      for (int tap = 0; tap < 9; ++tap)
+      for (int step = 0; step < 9; ++step) {
+        const int tap = perm16 ? (step % 3) * 3 + step / 3 : step;
         for (int g = 0; g < ng; ++g)
           for (int o = 0; o < 128; ++o)
             for (int j = 0; j < 8; ++j, ++i) {
@@ -357,6 +360,7 @@ void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch
               const int c = cc * chunk_ch + 8 * g + j, oc = slab * 128 + ch;
               dst[i] = f32_to_bf16_rne(k[((size_t)tap * cin + c) * cout + oc]);
             }
+      }
 }
 
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, int ablate, hipStream_t stream) {

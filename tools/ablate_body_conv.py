@@ -22,7 +22,7 @@ from dsen2_amd.DSen2Net import s2model            # noqa: E402
 bf = len(sys.argv) > 1 and sys.argv[1] == 'bf16'
 F, B, H, D = (256, 256, 32, 3) if bf else (128, 512, 32, 2)
 flat = W.random_he_uniform(10, 6, D, F, seed=1)
-masks = [0, 1, 3, 4, 8, 12, 15, 16, 31] if bf else [0, 1, 2, 3, 4, 8, 12, 15, 16, 31]
+masks = ([int(m) for m in os.environ['ABLATE_MASKS'].split(',')] if os.environ.get('ABLATE_MASKS') else [0, 1, 3, 4, 8, 12, 15, 16, 31]) if bf else [0, 1, 2, 3, 4, 8, 12, 15, 16, 31]
 models = {}
 for k in masks:
     _lib.diag_set(1, k)
