@@ -7,13 +7,17 @@
 // This kernel changes the three ratios that set that traffic:
 //
 //   1. ITEM = 16 rows x 32 columns of pixels x 128 output channels.  A weight chunk now feeds 512 pixels instead
-//      of 256: L2->LDS bytes per MFMA fall by 40 % (weights 288 KiB + input 153 KiB per 151 MFLOP), and a wave's
-//      64-channel x 128-pixel tile (4 x 8 accumulators) needs 12 ds_read_b128 per 32 MFMAs instead of 16.
+//      of 256: L2->LDS bytes per MFMA fall by 40 % (weights 288 KiB + input 153 KiB per 151 MFLOP).  A wave's tile
+//      is 64 channels x (8 rows x 16 columns) = 4 x 8 accumulators.
 //   2. STEP = (tap, 32 input channels) = one MFMA k-step: an 8 KiB weight chunk, so the weight ring holds 8 chunks
 //      and the stream runs SEVEN steps ahead.  vmcnt retires in issue order, so a wave that waits for a fresh DMA
-//      also waits for every older store; with a seven-step lead the waits of an item's first five steps target
+//      also waits for every older store; with a seven-step lead the waits of an item's first steps target
 //      DMAs issued BEFORE the previous item's epilogue and count its loads and stores as younger
 //      (vmcnt(63)): the stores get 2.5 us to drain instead of one step.
+//      The nine taps of a chunk are walked DX-MAJOR: the ten 16-pixel row fragments (8 rows + 2 halo rows) of one dx
+//      stay in registers for its three dy taps — 22 ds_read_b128 per 96 MFMAs (round 1: 48, tap-major: 36).  The
+//      board runs this kernel at its power cap, so LDS bytes saved are clock gained (profiles/r02_h_power.md).
+//      The workgroup synchronises after taps 1, 3, 5, 7, 8 only (barrier_after below).
 //   3. RESIDUAL STREAM AS TWO 16-BIT PLANES (conv-B).  The fp32 residual value u is kept as
 //      hi = (u + 0x8000) >> 16 (its bf16 rounding, ties away from zero) and lo = u & 0xffff: the pair restores u bit
 //      for bit (u = ((hi - (lo >> 15)) << 16) | lo, all mod 2^16 / 2^32), `hi` IS the next convolution's bf16
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   int stamp_it = 0;
   auto stamp = [&](int k) __attribute__((always_inline)) {
     if constexpr ((ABL & 32) != 0) {
+      if ((ABL & 64) != 0 && k != 0 && k != 19) return;      // 96: only the two loop-top stamps (clock measurement without the stamping overhead)
       if (p.diag && lid < 4 && (wave == 0 || wave == 7) && lane == 0)
         p.diag[(((size_t)lid * 2 + (wave == 7)) * 16 + (stamp_it & 15)) * 32 + k] =
             k == 19 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();      // slot 19: the 100 MHz counter
@@ -550,7 +555,7 @@ static hipError_t launch_body16w_feat(const ConvParams& p, int epilogue, int abl
     return epilogue == kEpiRelu       ? launch_body16w_one<F / 2, F, kEpiRelu, M>(p, stream, grid_cap)                  \
            : epilogue == kEpiResidual ? launch_body16w_one<F / 2, F, kEpiResidual, M>(p, stream, grid_cap)              \
                                       : launch_body16w_one<F / 2, F, kEpiResidualF32, M>(p, stream, grid_cap);
-  DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31) DSEN2_ABL(32)
+  DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31) DSEN2_ABL(32) DSEN2_ABL(96)
 #undef DSEN2_ABL
 #endif
   if (ablate != 0) return hipErrorInvalidValue;
