@@ -157,3 +157,61 @@ def test_full_tile_gather_then_recompose_is_the_identity(size, patch, border):
     crops = pats[:, :, border:patch - border, border:patch - border].contiguous()
     del pats
     assert torch.equal(P.recompose_device(crops, 0, (size, size)), img)
+
+
+def _fuzz_geometries(seed, n, sixty):
+    """Random (low-res extent, patch, border) triples the reference accepts: per-resolution patch and border come from
+    its floor divisions (patches.py:21-24, :85-90), so patch and border are multiples of the scale here; images from
+    smaller than one stride (a single clamped patch per axis) to ragged multi-tile extents."""
+    rng = np.random.default_rng(seed)
+    scale = 6 if sixty else 2
+    out = []
+    while len(out) < n:
+        p_lr = int(rng.integers(3, 17))
+        b_lr = int(rng.integers(0, (p_lr - 1) // 2 + 1))
+        stride = p_lr - 2 * b_lr
+        if stride < 1:
+            continue
+        lo_h = int(rng.integers(max(p_lr - 2 * b_lr, b_lr + 1), 5 * p_lr))
+        lo_w = int(rng.integers(max(p_lr - 2 * b_lr, b_lr + 1), 5 * p_lr))
+        if lo_h + 2 * b_lr < p_lr or lo_w + 2 * b_lr < p_lr or b_lr > min(lo_h, lo_w):   # np.pad('symmetric') handles b <= extent
+            continue
+        out.append((lo_h, lo_w, p_lr * scale, b_lr * scale))
+    return out
+
+
+@pytest.mark.parametrize('sixty', [False, True])
+def test_tiling_geometry_fuzz_matches_oracle(sixty):
+    """Seeded sweep over 40 geometries (ragged extents, one-patch images, zero borders, borders up to half a patch):
+    every crop is bit-exact against the oracle's restatement of patches.py:19-156, the up-sampled bands within the
+    float32-coordinate tolerance, and recompose_images inverts the tiling of the 10 m image exactly."""
+    from dsen2_amd import patches as gp
+    rng = np.random.default_rng(77 + sixty)
+    for lo_h, lo_w, patch, border in _fuzz_geometries(1234 + sixty, 40, sixty):
+        s = 6 if sixty else 2
+        d10 = rng.integers(0, 13110, size=(lo_h * s, lo_w * s, 4)).astype(np.float32)
+        if sixty:
+            d20 = rng.integers(0, 13110, size=(lo_h * 3, lo_w * 3, 6)).astype(np.float32)
+            d60 = rng.integers(0, 13110, size=(lo_h, lo_w, 2)).astype(np.float32)
+            got = gp.get_test_patches60(d10, d20, d60, patchSize=patch, border=border)
+            want = po.get_test_patches60(d10, d20, d60, patchSize=patch, border=border, f32_coords=True)
+            raw = gp.get_test_patches60(d10, d20, d60, patchSize=patch, border=border, interp=False)
+            raw_want = po.get_test_patches60(d10, d20, d60, patchSize=patch, border=border, interp=False)
+        else:
+            d20 = rng.integers(0, 13110, size=(lo_h, lo_w, 6)).astype(np.float32)
+            got = gp.get_test_patches(d10, d20, patchSize=patch, border=border)
+            want = po.get_test_patches(d10, d20, patchSize=patch, border=border, f32_coords=True)
+            raw = gp.get_test_patches(d10, d20, patchSize=patch, border=border, interp=False)
+            raw_want = po.get_test_patches(d10, d20, patchSize=patch, border=border, interp=False)
+        tag = 'lo=%dx%d patch=%d border=%d' % (lo_h, lo_w, patch, border)
+        assert got[0].shape == want[0].shape, tag
+        assert np.array_equal(got[0], want[0]), tag
+        for a, b in zip(raw[1:], raw_want[1:]):
+            assert np.array_equal(a, b), tag
+        for a, b in zip(got[1:], want[1:]):
+            np.testing.assert_allclose(a, b, err_msg=tag, **TIGHT)
+        rec = quiet(gp.recompose_images, got[0], border=border, size=d10.shape)
+        rec_want = quiet(po.recompose_images, want[0], border, d10.shape)
+        assert np.array_equal(rec, rec_want), tag
+        if got[0].shape[0] > 1 and min(d10.shape[:2]) >= patch - 2 * border:
+            assert np.array_equal(rec, d10), tag
