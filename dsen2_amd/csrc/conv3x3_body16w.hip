@@ -108,7 +108,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   constexpr bool kW = !(ABL & 4), kIn = !(ABL & 8);
   constexpr bool kRes = EPI != kEpiRelu;
   // vector-memory operations of one epilogue (per wave): 16 groups of 8 channels x (stores + residual loads)
-  constexpr int E_OPS = ((ABL & 1) ? 0 : (EPI == kEpiRelu ? 16 : 32)) + (kRes && !(ABL & 2) ? 32 : 0);
+  // (diagnostic mask 128: the ISSUING waves 0-3 skip their epilogue stores, the compute-only waves keep theirs — the
+  // waits exist in the issuers' code only, so E_OPS is theirs; mask 256: the other way round)
+  constexpr int E_OPS = ((ABL & (1 | 128)) ? 0 : (EPI == kEpiRelu ? 16 : 32)) + (kRes && !(ABL & 2) ? 32 : 0);
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const in_s = reinterpret_cast<char*>(smem);                       // [2][4][QS][16 B]
@@ -281,7 +283,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
             v1[e] = fmaxf(v1[e], 0.f);
           }
           const u32x4 hv = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-          if constexpr (!(ABL & 1))
+          if constexpr ((ABL & 384) != 0) {
+            if ((wave < 4) == ((ABL & 128) != 0)) asm volatile("" ::"v"(hv)); else __builtin_amdgcn_raw_buffer_store_b128(hv, out_rsrc, plane_off(pr, pb), 0, 0);
+          } else if constexpr (!(ABL & 1))
             __builtin_amdgcn_raw_buffer_store_b128(hv, out_rsrc, plane_off(pr, pb), 0, 0);
           else
             asm volatile("" ::"v"(hv));
@@ -337,7 +341,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
               oh[k] = h_;
               ol[k] = l_;
             }
-            if constexpr (!(ABL & 1)) {
+            if constexpr ((ABL & 384) != 0) {
+              if ((wave < 4) == ((ABL & 128) != 0)) {
+                asm volatile("" ::"v"(oh), "v"(ol));
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b128(oh, hi_rsrc, eo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ol, lo_rsrc, eo, 0, kResPolicy);
+              }
+            } else if constexpr (!(ABL & 1)) {
               __builtin_amdgcn_raw_buffer_store_b128(oh, hi_rsrc, eo, 0, 0);
               __builtin_amdgcn_raw_buffer_store_b128(ol, lo_rsrc, eo, 0, kResPolicy);
             } else {
@@ -555,7 +566,7 @@ static hipError_t launch_body16w_feat(const ConvParams& p, int epilogue, int abl
     return epilogue == kEpiRelu       ? launch_body16w_one<F / 2, F, kEpiRelu, M>(p, stream, grid_cap)                  \
            : epilogue == kEpiResidual ? launch_body16w_one<F / 2, F, kEpiResidual, M>(p, stream, grid_cap)              \
                                       : launch_body16w_one<F / 2, F, kEpiResidualF32, M>(p, stream, grid_cap);
-  DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31) DSEN2_ABL(32) DSEN2_ABL(96)
+  DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31) DSEN2_ABL(32) DSEN2_ABL(96) DSEN2_ABL(128) DSEN2_ABL(256)
 #undef DSEN2_ABL
 #endif
   if (ablate != 0) return hipErrorInvalidValue;
