@@ -62,8 +62,9 @@ void pack_out_valu_weights_host(const float* kernel_hwio, int cin, int cout, flo
 // DMA-fed fp32 kernel (conv3x3_body32.hip): F = 128 or 256, images < 2 GiB; weights packed with KC=32, NT=128
 bool body32_supports(const ConvParams& p, int cout);
 hipError_t launch_conv3x3_body32(const ConvParams& p, int feat, int epilogue, int sub, int ablate, hipStream_t stream);
-// kernel HWIO fp32 -> bf16 packed [slab][cc (chunk_ch channels)][tap][g (groups of 8 ch)][o(128)][8]; dst holds
-// 9*cin*cout uint16.  perm16: row o of a slab holds output channel 32*(o>>5) + 8*((o&15)>>2) + 4*((o>>4)&1) + (o&3),
+// kernel HWIO fp32 -> bf16 packed [slab][cc (chunk_ch channels)][step][g (groups of 8 ch)][o(128)][8]; dst holds
+// 9*cin*cout uint16.  step = tap, except with perm16 (conv3x3_body16w.hip walks the taps dx-major: step s carries tap
+// (dy, dx) = (s % 3, s / 3)).  perm16: row o of a slab holds output channel 32*(o>>5) + 8*((o&15)>>2) + 4*((o>>4)&1) + (o&3),
 // so that the two 16-row accumulators of a 32-channel pair give a lane 8 consecutive channels (conv3x3_body16w.hip)
 void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, int chunk_ch, bool perm16, uint16_t* dst);
 // bf16-operand body convolution, wide tile (conv3x3_body16w.hip), F = 128 or 256.  16-bit tensors are BLOCKED:
