@@ -17,7 +17,7 @@
 //      The nine taps of a chunk are walked DX-MAJOR: the ten 16-pixel row fragments (8 rows + 2 halo rows) of one dx
 //      stay in registers for its three dy taps — 22 ds_read_b128 per 96 MFMAs (round 1: 48, tap-major: 36).  The
 //      board runs this kernel at its power cap, so LDS bytes saved are clock gained (profiles/r02_h_power.md).
-//      The workgroup synchronises after taps 1, 3, 5, 7, 8 only (barrier_after below).
+//      The workgroup synchronises after steps 1, 3, 5, 7, 8 of a chunk only (barrier_after below).
 //   3. RESIDUAL STREAM AS TWO 16-BIT PLANES (conv-B).  The fp32 residual value u is kept as
 //      hi = (u + 0x8000) >> 16 (its bf16 rounding, ties away from zero) and lo = u & 0xffff: the pair restores u bit
 //      for bit (u = ((hi - (lo >> 15)) << 16) | lo, all mod 2^16 / 2^32), `hi` IS the next convolution's bf16
@@ -53,7 +53,7 @@ constexpr int IN_ROUNDS = 10;               // DMA rounds per issuing wave and c
 constexpr int WCH_BYTES = 32 * 128 * 2;     // one weight chunk: [4 k-groups][128 rows][16 B] = 8 KiB
 constexpr int RING = 8;                     // weight ring slots
 constexpr int LEAD = RING - 1;              // chunk c + LEAD is issued in step c
-constexpr int THREADS = 512;                // 8 waves: (channel half) x (4-row strip)
+constexpr int THREADS = 512;                // 8 waves: (channel half) x (pixel quarter: 8 rows x 16 columns)
 constexpr int MB = 4, PB = 8;               // per wave: 4 x 16 channels, 8 x 16 pixels (8 rows of one 16-column half)
 constexpr int XR = PB + 2;                  // halo-row fragments kept per dx
 constexpr size_t LDS_BYTES = (size_t)2 * IN_BYTES + (size_t)RING * WCH_BYTES + 256 * 4;
@@ -67,30 +67,31 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 // ISSUING WAVES.  Waves w and w + 4 share a SIMD.  A DMA costs its wave address arithmetic plus ~100 cycles of issue,
 // and a wave in that phase issues no MFMAs; with every wave issuing its share right after the barrier, both waves
 // of a SIMD were in that phase together and the matrix pipe idled ~17 % of every step.  Waves 0-3 therefore issue
-// ALL DMAs (two weight pieces and, in taps 0-4, two input rounds per step) while their SIMD partners 4-7 go straight
+// ALL DMAs (two weight pieces and, in steps 0-4 of a chunk, two input rounds per step) while their SIMD partners 4-7 go straight
 // to their MFMAs and never wait on vmcnt at all (publication = the issuing wave's wait + the step's barrier).
 constexpr int W_PER_STEP = 2;               // weight pieces an issuing wave moves per step (its own and +4)
-constexpr int rounds_in_tap(int t) { return t < 5 ? 2 : 0; }
-constexpr int first_round_of_tap(int t) { return 2 * t; }
-// BARRIERS.  The workgroup synchronises after taps 1, 3, 5, 7 and 8 of every chunk — five barriers per nine steps, not
-// nine (each one drains the matrix pipe of both waves of a SIMD).  What a barrier after tap t must publish is every
+constexpr int rounds_in_step(int t) { return t < 5 ? 2 : 0; }
+constexpr int first_round_of_step(int t) { return 2 * t; }
+// BARRIERS.  (t below = index of a step inside its chunk, 0-8; the tap it computes is (dy, dx) = (t % 3, t / 3).)
+// The workgroup synchronises after steps 1, 3, 5, 7 and 8 of every chunk — five barriers per nine steps, not
+// nine (each one drains the matrix pipe of both waves of a SIMD).  What a barrier after step t must publish is every
 // weight chunk read before the next barrier: fragments of chunk s+1 are read DURING step s, so the barrier after
-// step s = tap t covers chunks up to s + wait_depth(t) (3, or 2 after tap 7 because tap 8 has its own barrier).
+// step s (index t in its chunk) covers chunks up to s + wait_depth(t) (3, or 2 after t = 7 because 8 has its own barrier).
 // Ring reuse stays safe with LEAD = 7: the DMA issued at the start of step s overwrites chunk s-1, whose fragments
 // were read during step s-2, and between any step s-2 and step s lies a barrier of that pattern.
 constexpr bool barrier_after(int t) { return t == 8 || (t & 1) != 0; }
 constexpr int wait_depth(int t) { return t == 7 ? 2 : 3; }
 // vector-memory operations an issuing wave issues AFTER the weight DMAs of step s+depth-LEAD up to the end of step s
-// (tap t): the weight DMAs of the LEAD-depth steps up to s and those steps' input rounds (issued before the step's
+// (index t): the weight DMAs of the LEAD-depth steps up to s and those steps' input rounds (issued before the step's
 // weight DMAs).  vmcnt(N) at the end of step s therefore retires the wave's pieces of weight chunk s+depth and
 // everything older.
 constexpr int younger_ops(int t, int depth, bool has_w, bool has_in) {
   int n = 0;
-  for (int j = 0; j < LEAD - depth; ++j) n += (has_w ? W_PER_STEP : 0) + (has_in ? rounds_in_tap((t - j + 9) % 9) : 0);
+  for (int j = 0; j < LEAD - depth; ++j) n += (has_w ? W_PER_STEP : 0) + (has_in ? rounds_in_step((t - j + 9) % 9) : 0);
   return n;
 }
-// the input chunk staged in taps 0-4 is first read during tap 8: by the end of tap 7 everything up to tap 4's last
-// input round must have landed, i.e. all but the weight DMAs of taps 4-7
+// the input chunk staged in steps 0-4 is first read during step 8: by the end of step 7 everything up to step 4's last
+// input round must have landed, i.e. all but the weight DMAs of steps 4-7
 constexpr int younger_than_input(bool has_w) { return has_w ? 4 * W_PER_STEP : 0; }
 
 }  // namespace
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
       read_rows(in_s);
     }
     // These reads of chunk 0 happen IN the item's first step, not one step earlier like every other fragment read,
-    // and step 1's weight DMA reuses chunk 0's ring slot with no barrier after tap 0: synchronise here, once per item.
+    // and step 1's weight DMA reuses chunk 0's ring slot with no barrier after step 0: synchronise here, once per item.
     if constexpr (!(ABL & 16)) __syncthreads();
     stamp(2);
 
@@ -436,27 +437,27 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
       const bool last_cc = cc == NCC - 1;
       const int in_cc = last_cc ? 0 : cc + 1;
       if (ISSUER && last_cc && have_next_item) set_stage_item(item + G);
-      auto step = [&](auto tap_c) __attribute__((always_inline)) {
-        constexpr int tap = decltype(tap_c)::value;
+      auto step = [&](auto st_c) __attribute__((always_inline)) {
+        constexpr int st = decltype(st_c)::value;        // index of the step inside its chunk
         const int nx_slot = mf_slot == RING - 1 ? 0 : mf_slot + 1;
         const char* const wb_nx = w_s + nx_slot * WCH_BYTES;
         // this step's DMAs: input rounds first, then the weight chunk LEAD steps ahead
         if constexpr (ISSUER && kIn) {
 #pragma unroll
-          for (int r = 0; r < rounds_in_tap(tap); ++r) issue_in((cc + 1) & 1, first_round_of_tap(tap) + r, in_cc);
+          for (int r = 0; r < rounds_in_step(st); ++r) issue_in((cc + 1) & 1, first_round_of_step(st) + r, in_cc);
         }
         if constexpr (ISSUER && kW) issue_w();
-        // Step s of a chunk computes tap (dy, dx) = (s % 3, s / 3): dx-major, so that the XR row fragments of one dx
+        // Step st of a chunk computes tap (dy, dx) = (st % 3, st / 3): dx-major, so that the XR row fragments of one dx
         // serve three steps (22 fragment reads per three steps instead of 36).  Fragments are refilled in place as
         // soon as their last MFMA of this dx has issued: row 0 after (MB-1, 0) of dy = 0, row 1 after (MB-1, 0) of
         // dy = 1, row pb + 2 after (MB-1, pb) of dy = 2; weight fragment mb after its 8 MFMAs.  The last dx of a chunk
         // refills from the NEXT chunk's buffer, which is only complete after step 7's barrier: its rows 0 and 1 are
         // read at the start of step 8.  (An item's last step reads the next item's first fragments too; they are
         // read again after the epilogue, which needs the registers.)
-        constexpr int dy = tap % 3, dx = tap / 3;
+        constexpr int dy = st % 3, dx = st / 3;
         const char* const xb_nx = (dx < 2 ? ib + (dx + 1) * 16 : ib_next) + x_lane;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (tap == 8) {
+        if constexpr (st == 8) {
           x_row[0] = *reinterpret_cast<const f32x4*>(xb_nx);
           x_row[1] = *reinterpret_cast<const f32x4*>(xb_nx + HW * 16);
           __builtin_amdgcn_sched_barrier(0);
@@ -484,13 +485,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
         // ISSUER, before a barrier: retire this wave's pieces of the weight chunk wait_depth steps ahead and everything
         // older; while that chunk was issued before the previous epilogue (the item's first steps), the epilogue's
         // loads and stores are younger than it and stay in flight.  Workers have no DMA of their own to wait for.
-        if constexpr (barrier_after(tap)) {
+        if constexpr (barrier_after(st)) {
           if constexpr (ISSUER) {
-            constexpr int kD = wait_depth(tap);
-            constexpr int kN0 = younger_ops(tap, kD, kW, kIn);
-            constexpr int kN = (tap == 7 && kIn && younger_than_input(kW) < kN0) ? younger_than_input(kW) : kN0;
+            constexpr int kD = wait_depth(st);
+            constexpr int kN0 = younger_ops(st, kD, kW, kIn);
+            constexpr int kN = (st == 7 && kIn && younger_than_input(kW) < kN0) ? younger_than_input(kW) : kN0;
             constexpr int kNE = kN + E_OPS < 63 ? kN + E_OPS : 63;
-            if constexpr (tap + kD < LEAD && kNE != kN) {
+            if constexpr (st + kD < LEAD && kNE != kN) {
               // vmcnt(kNE) in the item's first chunk, vmcnt(kN) otherwise.  The scalar branch lives inside ONE asm
               // statement so that the nine-step body stays a single basic block (split into blocks, hipcc's register
               // allocator shuffles the accumulators between them and spills into the DMA-counted vmcnt stream).
@@ -504,9 +505,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
           if constexpr (!(ABL & 16)) __syncthreads();
         }
         if constexpr ((ABL & 32) != 0) {
-          if (cc == 0) stamp(3 + tap);
-          if (tap == 8 && cc == 1) stamp(12);
-          if (tap == 8 && cc == NCC - 1) stamp(13);
+          if (cc == 0) stamp(3 + st);
+          if (st == 8 && cc == 1) stamp(12);
+          if (st == 8 && cc == NCC - 1) stamp(13);
         }
       };
       step(std::integral_constant<int, 0>{});
