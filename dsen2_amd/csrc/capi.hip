@@ -458,18 +458,23 @@ int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, c
   auto launch = [&]() -> hipError_t {
     return L.bf16 ? launch_bf16_body(p, m->feat, epi, m->tune, stream) : launch_conv3x3(p, L.geom, L.epilogue, abl, stream);
   };
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  // the two events are destroyed on every path
+  struct Events {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } ev;
+  HIP_TRY(hipEventCreate(&ev.e0));
+  HIP_TRY(hipEventCreate(&ev.e1));
   HIP_TRY(launch());   // warm-up
-  HIP_TRY(hipEventRecord(e0, stream));
+  HIP_TRY(hipEventRecord(ev.e0, stream));
   for (int i = 0; i < iters; ++i) HIP_TRY(launch());
-  HIP_TRY(hipEventRecord(e1, stream));
-  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventRecord(ev.e1, stream));
+  HIP_TRY(hipEventSynchronize(ev.e1));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
   *ms_per_launch = ms / iters;
   return DSEN2_OK;
 }
