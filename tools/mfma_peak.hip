@@ -40,6 +40,32 @@ __global__ __launch_bounds__(512, 2) void bf16_loop(const uint4* __restrict__ sr
     if (blockIdx.x == 0 && t == 0) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
 }
 
+// the 32x32x16 form of the same tile: 2 A fragments x 4 B fragments -> 8 accumulators of 16 registers
+__global__ __launch_bounds__(512, 2) void bf16_loop_32(const uint4* __restrict__ src, float* __restrict__ sink, int iters,
+                                                       unsigned long long* __restrict__ clk) {
+    const int t = threadIdx.x;
+    bf16x8 a[2], b[4];
+    for (int i = 0; i < 2; ++i) { uint4 v = src[(t * 12 + i) & 4095]; a[i] = *reinterpret_cast<bf16x8*>(&v); }
+    for (int i = 0; i < 4; ++i) { uint4 v = src[(t * 12 + 4 + i) & 4095]; b[i] = *reinterpret_cast<bf16x8*>(&v); }
+    f32x16 acc[2][4];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+    unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int k = 0; k < 16; ++k) s += acc[i][j][k];
+    if (s == 123.456f) sink[t] = s;
+    if (blockIdx.x == 0 && t == 0) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
+}
+
 __global__ __launch_bounds__(512, 2) void f32_loop(const float* __restrict__ src, float* __restrict__ sink, int iters,
                                                    unsigned long long* __restrict__ clk) {
     const int t = threadIdx.x;
@@ -141,6 +167,7 @@ int main(int argc, char** argv) {
     const V vs[] = {
         {"bf16_16x16x32_random", 0, d_rand, 32.0 * 2 * 16 * 16 * 32},
         {"bf16_16x16x32_zeros", 0, d_zero, 32.0 * 2 * 16 * 16 * 32},
+        {"bf16_32x32x16_random", 32, d_rand, 16.0 * 2 * 32 * 32 * 16},
         {"bf16_lds_reads_12_per_32", 12, d_rand, 32.0 * 2 * 16 * 16 * 32},
         {"bf16_lds_reads_7_per_32", 7, d_rand, 32.0 * 2 * 16 * 16 * 32},
         {"bf16_lds_reads_4_per_32", 4, d_rand, 32.0 * 2 * 16 * 16 * 32},
@@ -158,7 +185,8 @@ int main(int argc, char** argv) {
             while (total_ms < budget * 1e3) {
                 CHECK(hipEventRecord(e0, 0));
                 for (int k = 0; k < 20; ++k) {
-                    if (v.kind == 12) bf16_lds_loop<12><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
+                    if (v.kind == 32) bf16_loop_32<<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
+                    else if (v.kind == 12) bf16_lds_loop<12><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
                     else if (v.kind == 7) bf16_lds_loop<7><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
                     else if (v.kind == 4) bf16_lds_loop<4><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
                     else if (v.kind == 0) bf16_loop<<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);

@@ -96,7 +96,7 @@ def main():
     if configs and configs[0] == '--mfma':
         # calibration: tools/mfma_peak.hip (built to build/mfma_peak), one variant per child so each gets its own samples
         exe = os.path.join(ROOT, 'build', 'mfma_peak')
-        for var in ('bf16_16x16x32_random', 'bf16_16x16x32_zeros', 'bf16_lds_reads_12_per_32', 'bf16_lds_reads_7_per_32',
+        for var in ('bf16_16x16x32_random', 'bf16_32x32x16_random', 'bf16_16x16x32_zeros', 'bf16_lds_reads_12_per_32', 'bf16_lds_reads_7_per_32',
                     'bf16_lds_reads_4_per_32', 'f32_32x32x2_random', 'f32_32x32x2_zeros'):
             child = subprocess.Popen([exe, '4', var], stdout=subprocess.PIPE, text=True)
             rows = []
