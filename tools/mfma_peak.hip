@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+template <int ORDER>
 __global__ __launch_bounds__(512, 2) void bf16_loop(const uint4* __restrict__ src, float* __restrict__ sink, int iters,
                                                     unsigned long long* __restrict__ clk) {
     const int t = threadIdx.x;
@@ -28,10 +29,14 @@ __global__ __launch_bounds__(512, 2) void bf16_loop(const uint4* __restrict__ sr
     unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int n = 0; n < 32; ++n) {
+            // 0: A fragment shared by 8 consecutive MFMAs (the product kernel's order); 1: B fragment shared by 4;
+            // 2: both operands change with every MFMA
+            const int i = ORDER == 0 ? n / 8 : ORDER == 1 ? n % 4 : n % 4;
+            const int j = ORDER == 0 ? n % 8 : ORDER == 1 ? n / 4 : (n / 4 + n % 4 * 2 + n) % 8;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
@@ -167,6 +172,8 @@ int main(int argc, char** argv) {
     const V vs[] = {
         {"bf16_16x16x32_random", 0, d_rand, 32.0 * 2 * 16 * 16 * 32},
         {"bf16_16x16x32_zeros", 0, d_zero, 32.0 * 2 * 16 * 16 * 32},
+        {"bf16_16x16x32_random_b_outer", 101, d_rand, 32.0 * 2 * 16 * 16 * 32},
+        {"bf16_16x16x32_random_diagonal", 102, d_rand, 32.0 * 2 * 16 * 16 * 32},
         {"bf16_32x32x16_random", 32, d_rand, 16.0 * 2 * 32 * 32 * 16},
         {"bf16_lds_reads_12_per_32", 12, d_rand, 32.0 * 2 * 16 * 16 * 32},
         {"bf16_lds_reads_7_per_32", 7, d_rand, 32.0 * 2 * 16 * 16 * 32},
@@ -189,7 +196,9 @@ int main(int argc, char** argv) {
                     else if (v.kind == 12) bf16_lds_loop<12><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
                     else if (v.kind == 7) bf16_lds_loop<7><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
                     else if (v.kind == 4) bf16_lds_loop<4><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
-                    else if (v.kind == 0) bf16_loop<<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
+                    else if (v.kind == 101) bf16_loop<1><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
+                    else if (v.kind == 102) bf16_loop<2><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
+                    else if (v.kind == 0) bf16_loop<0><<<grid, 512>>>((const uint4*)v.src, sink, iters, clk);
                     else f32_loop<<<grid, 512>>>((const float*)v.src, sink, iters, clk);
                 }
                 CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
