@@ -80,6 +80,12 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     const float* src0 = in + p * (size_t)h * w + (size_t)r0 * w;
     const float* src1 = in + p * (size_t)h * w + (size_t)r1 * w;
     float res[4];
+    // The four IEEE divisions of the samples by 30000 are the kernel's main cost, and consecutive output columns
+    // mostly share their source columns (x2: three distinct columns per four outputs, x6: two): a column's pair of
+    // quotients (both rows) is computed once and carried to the next output.  Same operations on the same values:
+    // the results are the bits of the unshared form.
+    int pc0 = -1, pc1 = -1;
+    double ptl = 0.0, pbl = 0.0, ptr = 0.0, pbr = 0.0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int oj = oj0 + e < ow ? oj0 + e : ow - 1;
@@ -87,8 +93,15 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
       const float cf = floorf(c);
       const int c0 = mirror_index((int)cf, w), c1 = mirror_index((int)ceilf(c), w);
       const double dc = (double)__fsub_rn(c, cf);
-      const double tl = (double)__fdiv_rn(src0[c0], 30000.0f), tr = (double)__fdiv_rn(src0[c1], 30000.0f);
-      const double bl = (double)__fdiv_rn(src1[c0], 30000.0f), br = (double)__fdiv_rn(src1[c1], 30000.0f);
+      double tl, bl, tr, br;
+      if (c0 == pc0) { tl = ptl; bl = pbl; }
+      else if (c0 == pc1) { tl = ptr; bl = pbr; }
+      else { tl = (double)__fdiv_rn(src0[c0], 30000.0f); bl = (double)__fdiv_rn(src1[c0], 30000.0f); }
+      if (c1 == c0) { tr = tl; br = bl; }
+      else if (c1 == pc1) { tr = ptr; br = pbr; }
+      else if (c1 == pc0) { tr = ptl; br = pbl; }
+      else { tr = (double)__fdiv_rn(src0[c1], 30000.0f); br = (double)__fdiv_rn(src1[c1], 30000.0f); }
+      pc0 = c0; pc1 = c1; ptl = tl; pbl = bl; ptr = tr; pbr = br;
       const double top = (1.0 - dc) * tl + dc * tr;
       const double bot = (1.0 - dc) * bl + dc * br;
       const float v = __fmul_rn((float)((1.0 - dr) * top + dr * bot), 30000.0f);
