@@ -2,8 +2,9 @@
 // low-resolution skip input, NHWC in, NCHW out (utils/DSen2Net.py:35,38,41) — on the VECTOR units.
 //
 // With 6 (or 2) output channels a matrix-core tile is mostly padding: a 32-wide MFMA block 81 % (94 %), the
-// 16x16x4 form (round 1's kernel: 171 us at the bench config) still 62 %.  The f32 vector rate equals the f32
-// matrix rate on gfx950 (157.3 TFLOP/s) and a vector kernel pads nothing: 122 us, same bits.
+// 16x16x4 form (round 1's kernel: 171 us at the bench config) still 62 %.  A vector kernel pads nothing (v_fma_f32
+// with the weight as scalar operand: 78.6 TFLOP/s, half the matrix rate): 122 us, same bits.  The packed
+// v_pk_fma_f32 form and other restructurings are in experiments/README.md (bit-identical, none faster).
 #include "dsen2_internal.h"
 
 namespace dsen2 {
