@@ -63,57 +63,92 @@ __device__ __forceinline__ int mirror_index(int i, int dim) {
   return i;
 }
 
-// One thread per group of 4 consecutive output columns of one output row: the row taps are computed once, the
-// four results leave as one 16-byte store when the row length allows it.
+// One thread = 4 consecutive output columns x kUpRows consecutive output rows of one plane.  The reference blends
+// horizontally first (top = row r0, bot = row r1, same formula) and then vertically, so the horizontal blend H[r][oj] of
+// an input row is the same number whichever output row asks for it: a thread keeps the two most recent H rows (an
+// up-sampler's consecutive output rows use (k, k+1), (k, k+1), (k+1, k+2), ...) and, inside a row, a source column's
+// quotient by 30000 once per four outputs.  Same operations on the same values as the one-output-at-a-time form:
+// the results are its bits (checked against the previous library on ragged shapes, tools/ history; the golden
+// vectors of tests/test_gpu_patches.py pin both against skimage).
+constexpr int kUpRows = 8;
+
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                       size_t total_groups, int h, int w, int oh, int ow, int gpr,
-                                                       float sy, float oy, float sx, float ox, float post_div) {
-  const size_t grp_plane = (size_t)oh * gpr;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_groups; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t p = i / grp_plane;
-    const int rem = (int)(i - p * grp_plane);
-    const int oi = rem / gpr, oj0 = (rem - oi * gpr) * 4;
-    const float r = __fadd_rn(__fmul_rn(sy, (float)oi), oy);
-    const float rf = floorf(r);
-    const int r0 = mirror_index((int)rf, h), r1 = mirror_index((int)ceilf(r), h);
-    const double dr = (double)__fsub_rn(r, rf);
-    const float* src0 = in + p * (size_t)h * w + (size_t)r0 * w;
-    const float* src1 = in + p * (size_t)h * w + (size_t)r1 * w;
-    float res[4];
-    // The four IEEE divisions of the samples by 30000 are the kernel's main cost, and consecutive output columns
-    // mostly share their source columns (x2: three distinct columns per four outputs, x6: two): a column's pair of
-    // quotients (both rows) is computed once and carried to the next output.  Same operations on the same values:
-    // the results are the bits of the unshared form.
-    int pc0 = -1, pc1 = -1;
-    double ptl = 0.0, pbl = 0.0, ptr = 0.0, pbr = 0.0;
+                                                       size_t total_threads, int h, int w, int oh, int ow, int gpr,
+                                                       int row_blocks, float sy, float oy, float sx, float ox,
+                                                       float post_div) {
+  const size_t per_plane = (size_t)row_blocks * gpr;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_threads; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / per_plane;
+    const int rem = (int)(i - p * per_plane);
+    const int rb = rem / gpr, oj0 = (rem - rb * gpr) * 4;
+    const float* const plane = in + p * (size_t)h * w;
+    // column taps of the four outputs (identical for every row)
+    int c0[4], c1[4];
+    double dc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int oj = oj0 + e < ow ? oj0 + e : ow - 1;
       const float c = __fadd_rn(__fmul_rn(sx, (float)oj), ox);
       const float cf = floorf(c);
-      const int c0 = mirror_index((int)cf, w), c1 = mirror_index((int)ceilf(c), w);
-      const double dc = (double)__fsub_rn(c, cf);
-      double tl, bl, tr, br;
-      if (c0 == pc0) { tl = ptl; bl = pbl; }
-      else if (c0 == pc1) { tl = ptr; bl = pbr; }
-      else { tl = (double)__fdiv_rn(src0[c0], 30000.0f); bl = (double)__fdiv_rn(src1[c0], 30000.0f); }
-      if (c1 == c0) { tr = tl; br = bl; }
-      else if (c1 == pc1) { tr = ptr; br = pbr; }
-      else if (c1 == pc0) { tr = ptl; br = pbl; }
-      else { tr = (double)__fdiv_rn(src0[c1], 30000.0f); br = (double)__fdiv_rn(src1[c1], 30000.0f); }
-      pc0 = c0; pc1 = c1; ptl = tl; pbl = bl; ptr = tr; pbr = br;
-      const double top = (1.0 - dc) * tl + dc * tr;
-      const double bot = (1.0 - dc) * bl + dc * br;
-      const float v = __fmul_rn((float)((1.0 - dr) * top + dr * bot), 30000.0f);
-      res[e] = post_div == 1.0f ? v : __fdiv_rn(v, post_div);   // folds `p20 /= SCALE` (testing/supres.py:24)
+      c0[e] = mirror_index((int)cf, w);
+      c1[e] = mirror_index((int)ceilf(c), w);
+      dc[e] = (double)__fsub_rn(c, cf);
     }
-    float* dst = out + (p * oh + oi) * (size_t)ow + oj0;
-    if ((ow & 3) == 0) {
-      *reinterpret_cast<f32x4*>(dst) = f32x4{res[0], res[1], res[2], res[3]};
-    } else {
+    // horizontal blend of input row r at the four output columns
+    auto hrow = [&](int r, double (&H)[4]) {
+      const float* const src = plane + (size_t)r * w;
+      int pc0 = -1, pc1 = -1;
+      double pq0 = 0.0, pq1 = 0.0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (oj0 + e < ow) dst[e] = res[e];
+      for (int e = 0; e < 4; ++e) {
+        double q0, q1;
+        if (c0[e] == pc0) q0 = pq0;
+        else if (c0[e] == pc1) q0 = pq1;
+        else q0 = (double)__fdiv_rn(src[c0[e]], 30000.0f);
+        if (c1[e] == c0[e]) q1 = q0;
+        else if (c1[e] == pc1) q1 = pq1;
+        else if (c1[e] == pc0) q1 = pq0;
+        else q1 = (double)__fdiv_rn(src[c1[e]], 30000.0f);
+        pc0 = c0[e]; pc1 = c1[e]; pq0 = q0; pq1 = q1;
+        H[e] = (1.0 - dc[e]) * q0 + dc[e] * q1;
+      }
+    };
+    int ia = -1, ib = -1;                       // input rows held in Ha / Hb
+    double Ha[4], Hb[4];
+    bool a_older = true;                        // which of the two is replaced next
+    for (int k = 0; k < kUpRows; ++k) {
+      const int oi = rb * kUpRows + k;
+      if (oi >= oh) break;
+      const float r = __fadd_rn(__fmul_rn(sy, (float)oi), oy);
+      const float rf = floorf(r);
+      const int r0 = mirror_index((int)rf, h), r1 = mirror_index((int)ceilf(r), h);
+      const double dr = (double)__fsub_rn(r, rf);
+      // make both rows resident (never evicting the one the other tap needs)
+      if (r0 != ia && r0 != ib) {
+        if (a_older && ia != r1) { hrow(r0, Ha); ia = r0; a_older = false; }
+        else if (ib != r1) { hrow(r0, Hb); ib = r0; a_older = true; }
+        else { hrow(r0, Ha); ia = r0; a_older = false; }
+      }
+      if (r1 != ia && r1 != ib) {
+        if (ia != r0) { hrow(r1, Ha); ia = r1; a_older = false; }
+        else { hrow(r1, Hb); ib = r1; a_older = true; }
+      }
+      float res[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double top = r0 == ia ? Ha[e] : Hb[e];
+        const double bot = r1 == ia ? Ha[e] : Hb[e];
+        const float v = __fmul_rn((float)((1.0 - dr) * top + dr * bot), 30000.0f);
+        res[e] = post_div == 1.0f ? v : __fdiv_rn(v, post_div);   // folds `p20 /= SCALE` (testing/supres.py:24)
+      }
+      float* dst = out + (p * oh + oi) * (size_t)ow + oj0;
+      if ((ow & 3) == 0) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{res[0], res[1], res[2], res[3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (oj0 + e < ow) dst[e] = res[e];
+      }
     }
   }
 }
@@ -121,10 +156,11 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 hipError_t launch_upsample(const float* in, float* out, int planes, int h, int w, int oh, int ow, float post_div,
                            hipStream_t stream) {
   const int gpr = (ow + 3) / 4;                       // 4-column groups per output row
-  const size_t total = (size_t)planes * oh * gpr;
+  const int row_blocks = (oh + kUpRows - 1) / kUpRows;
+  const size_t total = (size_t)planes * row_blocks * gpr;
   const double fy = (double)h / oh, fx = (double)w / ow;
   hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, in, out, total, h, w, oh, ow, gpr,
-                     (float)fy, (float)(0.5 * fy - 0.5), (float)fx, (float)(0.5 * fx - 0.5), post_div);
+                     row_blocks, (float)fy, (float)(0.5 * fy - 0.5), (float)fx, (float)(0.5 * fx - 0.5), post_div);
   return hipGetLastError();
 }
 
