@@ -90,6 +90,13 @@ constexpr int younger_ops(int t, int depth, bool has_w, bool has_in) {
   for (int j = 0; j < LEAD - depth; ++j) n += (has_w ? W_PER_STEP : 0) + (has_in ? rounds_in_step((t - j + 9) % 9) : 0);
   return n;
 }
+// diagnostic mask 512: memory operations the trickled epilogue adds to step gs of an item (issued BEFORE the step's DMAs)
+constexpr int trickle_ops(int gs) { return (gs >= 0 && gs < 16 ? 2 : 0) + (gs >= 5 && gs < 21 ? 2 : 0); }
+constexpr int trickle_younger(int cc, int t, int depth) {
+  int n = 0;
+  for (int j = 0; j < LEAD - depth; ++j) n += trickle_ops(cc * 9 + t - j);
+  return n;
+}
 // the input chunk staged in steps 0-4 is first read during step 8: by the end of step 7 everything up to step 4's last
 // input round must have landed, i.e. all but the weight DMAs of steps 4-7
 constexpr int younger_than_input(bool has_w) { return has_w ? 4 * W_PER_STEP : 0; }
@@ -111,7 +118,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   // vector-memory operations of one epilogue (per wave): 16 groups of 8 channels x (stores + residual loads)
   // (diagnostic mask 128: the ISSUING waves 0-3 skip their epilogue stores, the compute-only waves keep theirs — the
   // waits exist in the issuers' code only, so E_OPS is theirs; mask 256: the other way round)
-  constexpr int E_OPS = ((ABL & (1 | 128)) ? 0 : (EPI == kEpiRelu ? 16 : 32)) + (kRes && !(ABL & 2) ? 32 : 0);
+  // diagnostic mask 512 (kEpiResidual only, timing only): the epilogue issues no memory operation; instead the item's 32
+  // residual loads and 32 stores are issued two + two per step inside the NEXT item's first 21 steps (loads in steps
+  // 0-15, stores five steps behind) — the traffic of a deferred epilogue without its register cost, to price one
+  constexpr bool kTrickle = (ABL & 512) != 0 && EPI == kEpiResidual;
+  constexpr int ABLE = kTrickle ? (ABL | 3) : ABL;
+  constexpr int E_OPS = ((ABLE & (1 | 128)) ? 0 : (EPI == kEpiRelu ? 16 : 32)) + (kRes && !(ABLE & 2) ? 32 : 0);
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const in_s = reinterpret_cast<char*>(smem);                       // [2][4][QS][16 B]
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
           const u32x4 hv = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
           if constexpr ((ABL & 384) != 0) {
             if ((wave < 4) == ((ABL & 128) != 0)) asm volatile("" ::"v"(hv)); else __builtin_amdgcn_raw_buffer_store_b128(hv, out_rsrc, plane_off(pr, pb), 0, 0);
-          } else if constexpr (!(ABL & 1))
+          } else if constexpr (!(ABLE & 1))
             __builtin_amdgcn_raw_buffer_store_b128(hv, out_rsrc, plane_off(pr, pb), 0, 0);
           else
             asm volatile("" ::"v"(hv));
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int pb = 2 * j + (g >> 1), pr = g & 1;
-          if constexpr (!(ABL & 2)) {
+          if constexpr (!(ABLE & 2)) {
             const unsigned eo = plane_off(pr, pb);
             rh[j][g] = __builtin_amdgcn_raw_buffer_load_b128(hi_rsrc, eo, 0, kResPolicy);
             rl[j][g] = __builtin_amdgcn_raw_buffer_load_b128(lo_rsrc, eo, 0, kResPolicy);
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
                 __builtin_amdgcn_raw_buffer_store_b128(oh, hi_rsrc, eo, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(ol, lo_rsrc, eo, 0, kResPolicy);
               }
-            } else if constexpr (!(ABL & 1)) {
+            } else if constexpr (!(ABLE & 1)) {
               __builtin_amdgcn_raw_buffer_store_b128(oh, hi_rsrc, eo, 0, 0);
               __builtin_amdgcn_raw_buffer_store_b128(ol, lo_rsrc, eo, 0, kResPolicy);
             } else {
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
           } else {
             const u32x4 o0 = {ov[0], ov[1], ov[2], ov[3]}, o1 = {ov[4], ov[5], ov[6], ov[7]};
             const unsigned eo = nhwc_f32_off(pr, pb);
-            if constexpr (!(ABL & 1)) {
+            if constexpr (!(ABLE & 1)) {
               // immediate soffset only (store-data hazard of buffer_store_dwordx4 with an SGPR soffset, experiments/README.md)
               __builtin_amdgcn_raw_buffer_store_b128(o0, f32_rsrc, eo, 0, 0);
               __builtin_amdgcn_raw_buffer_store_b128(o1, f32_rsrc, eo + 16u, 0, 0);
@@ -441,6 +453,35 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
         constexpr int st = decltype(st_c)::value;        // index of the step inside its chunk
         const int nx_slot = mf_slot == RING - 1 ? 0 : mf_slot + 1;
         const char* const wb_nx = w_s + nx_slot * WCH_BYTES;
+        if constexpr (kTrickle && !(ISSUER && (ABL & 1024))) {       // 1024: only the compute-only waves trickle
+          // group g = cc*9 + st of the item's 16 (pr, pb) groups: addresses of this item's own groups (the same pattern)
+          const Tile tt = tile_of(item);
+          const unsigned blk0 = (unsigned)((tt.slab * 128 + wn * 64 + 8 * q4) >> 3);
+          const unsigned bpix = (unsigned)((tt.ty0 + wrow) * p.w + tt.tx0 + wcol + l15);
+          const size_t ie = img_pix * COUT;
+          const auto hi_r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<float*>(p.aux)) + (size_t)tt.img * ie * 2, 0, (unsigned)(ie * 2), 0x00020000);
+          const auto lo_r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out2) + (size_t)tt.img * ie * 2, 0, (unsigned)(ie * 2), 0x00020000);
+          auto goff = [&](int g) -> unsigned {            // g may run past 15 at run time only in skipped branches
+            const int pr = g & 1, pb = (g >> 1) & 7;
+            return ((blk0 + 4u * pr) * (unsigned)img_pix + bpix + (unsigned)(pb * p.w)) * 16u & 0x7fffffffu;
+          };
+          // loads of group cc*9+st while cc*9+st < 16: cc == 0, or cc == 1 and st < 7
+          {
+            const unsigned off = goff(st + 9 * (cc & 1));
+            u32x4 d0, d1;
+            asm volatile("s_cmp_lt_u32 %4, %5\n\ts_cbranch_scc0 .Ldsen2_tl%=\n\tbuffer_load_dwordx4 %0, %2, %3, 0 offen nt\n\t"
+                         "buffer_load_dwordx4 %1, %2, %6, 0 offen nt\n.Ldsen2_tl%=:"
+                         : "=&v"(d0), "=&v"(d1) : "v"(off), "s"(hi_r), "s"(cc), "n"(st < 7 ? 2 : 1), "s"(lo_r) : "memory", "scc");
+          }
+          // stores of group cc*9+st-5 while 5 <= cc*9+st < 21: (cc == 0 and st >= 5), cc == 1, (cc == 2 and st < 3)
+          {
+            const unsigned off = goff(st + 9 * cc + 11);          // (g - 5) mod 16
+            constexpr int lo_cc = st >= 5 ? 0 : 1, hi_cc = st < 3 ? 3 : 2;     // issue iff lo_cc <= cc < hi_cc
+            asm volatile("s_cmp_ge_u32 %3, %4\n\ts_cbranch_scc0 .Ldsen2_ts%=\n\ts_cmp_lt_u32 %3, %5\n\ts_cbranch_scc0 .Ldsen2_ts%=\n\t"
+                         "buffer_store_dwordx4 %0, %1, %2, 0 offen\n\tbuffer_store_dwordx4 %0, %1, %6, 0 offen nt\n.Ldsen2_ts%=:"
+                         :: "v"(acc[0][st & 7]), "v"(off), "s"(hi_r), "s"(cc), "n"(lo_cc), "n"(hi_cc), "s"(lo_r) : "memory", "scc");
+          }
+        }
         // this step's DMAs: input rounds first, then the weight chunk LEAD steps ahead
         if constexpr (ISSUER && kIn) {
 #pragma unroll
@@ -491,7 +532,20 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
             constexpr int kN0 = younger_ops(st, kD, kW, kIn);
             constexpr int kN = (st == 7 && kIn && younger_than_input(kW) < kN0) ? younger_than_input(kW) : kN0;
             constexpr int kNE = kN + E_OPS < 63 ? kN + E_OPS : 63;
-            if constexpr (st + kD < LEAD && kNE != kN) {
+            if constexpr (kTrickle && !(ABL & 1024)) {
+              constexpr int kIn0 = (st == 7 && kIn && younger_than_input(kW) < kN0) ? 1 : 0;
+              // ops younger than the awaited DMA per chunk index (the input-bound wait of step 7 counts steps 5-7 only)
+              constexpr int t0 = kIn0 ? trickle_ops(5) + trickle_ops(6) + trickle_ops(7) : trickle_younger(0, st, kD);
+              constexpr int t1 = kIn0 ? trickle_ops(14) + trickle_ops(15) + trickle_ops(16) : trickle_younger(1, st, kD);
+              constexpr int t2 = kIn0 ? trickle_ops(23) + trickle_ops(24) + trickle_ops(25) : trickle_younger(2, st, kD);
+              constexpr int n0 = kN + t0 < 63 ? kN + t0 : 63, n1 = kN + t1 < 63 ? kN + t1 : 63, n2 = kN + t2 < 63 ? kN + t2 : 63;
+              asm volatile("s_cmp_lt_u32 %0, 3\n\ts_cbranch_scc0 .Ldsen2_b%=\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Ldsen2_c0%=\n\t"
+                           "s_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Ldsen2_c1%=\n\ts_waitcnt vmcnt(%4)\n\ts_branch .Ldsen2_e%=\n"
+                           ".Ldsen2_c0%=:\n\ts_waitcnt vmcnt(%2)\n\ts_branch .Ldsen2_e%=\n"
+                           ".Ldsen2_c1%=:\n\ts_waitcnt vmcnt(%3)\n\ts_branch .Ldsen2_e%=\n"
+                           ".Ldsen2_b%=:\n\ts_waitcnt vmcnt(%1)\n.Ldsen2_e%=:"
+                           ::"s"(cc), "n"(kN), "n"(n0), "n"(n1), "n"(n2) : "memory", "scc");
+            } else if constexpr (st + kD < LEAD && kNE != kN) {
               // vmcnt(kNE) in the item's first chunk, vmcnt(kN) otherwise.  The scalar branch lives inside ONE asm
               // statement so that the nine-step body stays a single basic block (split into blocks, hipcc's register
               // allocator shuffles the accumulators between them and spills into the DMA-counted vmcnt stream).
@@ -567,7 +621,7 @@ static hipError_t launch_body16w_feat(const ConvParams& p, int epilogue, int abl
     return epilogue == kEpiRelu       ? launch_body16w_one<F / 2, F, kEpiRelu, M>(p, stream, grid_cap)                  \
            : epilogue == kEpiResidual ? launch_body16w_one<F / 2, F, kEpiResidual, M>(p, stream, grid_cap)              \
                                       : launch_body16w_one<F / 2, F, kEpiResidualF32, M>(p, stream, grid_cap);
-  DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31) DSEN2_ABL(32) DSEN2_ABL(96) DSEN2_ABL(128) DSEN2_ABL(256)
+  DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31) DSEN2_ABL(32) DSEN2_ABL(96) DSEN2_ABL(128) DSEN2_ABL(256) DSEN2_ABL(512) DSEN2_ABL(1536)
 #undef DSEN2_ABL
 #endif
   if (ablate != 0) return hipErrorInvalidValue;
