@@ -66,3 +66,39 @@ def test_full_tile_three_ranks_gloo_uneven_shards():
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
     assert r['n_gpus'] == 3 and r['matches_single_rank'] is True
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys
+import torch
+import torch.distributed as td
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+td.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+assert td.get_backend() == 'nccl'
+# the collectives bench.py / dsen2_amd.dist issue, with the tensor placement they use (all on the GPU)
+w = torch.arange(1000, dtype=torch.float32, device=dev)
+td.broadcast(w, src=0)
+out = torch.full((8, 6, 32, 32), 3.0, device=dev)
+recv = torch.empty((8, 6, 32, 32), device=dev)
+h = td.gather(out, list(recv.chunk(1)), dst=0, async_op=True)
+h.wait()
+td.barrier()
+t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+td.all_reduce(t, op=td.ReduceOp.MAX)
+torch.cuda.synchronize()
+assert torch.equal(recv, out) and float(t) == 1.25 and float(w[999]) == 999.0
+td.destroy_process_group()
+print('rccl one rank ok')
+'''
+
+
+def test_rccl_initialises_and_runs_the_bench_collectives_on_one_rank():
+    """The only RCCL evidence a one-GPU box can give: backend "nccl" (= RCCL) initialises with the environment the
+    product sets (HSA_ENABLE_IPC_MODE_LEGACY=0, rendezvous on 127.0.0.1) and the collectives of bench.py and
+    dsen2_amd.dist (broadcast, asynchronous gather into chunks of one buffer, barrier, all_reduce MAX) run on device
+    tensors.  With one rank nothing crosses xGMI: the N>1 data path stays unmeasured (DESIGN.md §6)."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-c', _RCCL_ONE_RANK], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0 and 'rccl one rank ok' in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
