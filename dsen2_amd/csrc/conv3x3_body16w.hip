@@ -323,7 +323,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
           if constexpr (!(ABLE & 2)) {
             const unsigned eo = plane_off(pr, pb);
             rh[j][g] = __builtin_amdgcn_raw_buffer_load_b128(hi_rsrc, eo, 0, kResPolicy);
-            rl[j][g] = __builtin_amdgcn_raw_buffer_load_b128(lo_rsrc, eo, 0, kResPolicy);
+            if constexpr ((ABL & 2048) != 0) {       // 2048 (timing only): the lo plane at 8 bits — 8-byte pieces, half the bytes
+              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+              const u32x2 h8 = __builtin_amdgcn_raw_buffer_load_b64(lo_rsrc, eo >> 1, 0, kResPolicy);
+              rl[j][g] = u32x4{h8[0], h8[1], h8[0], h8[1]};
+            } else {
+              rl[j][g] = __builtin_amdgcn_raw_buffer_load_b128(lo_rsrc, eo, 0, kResPolicy);
+            }
           } else {
             rh[j][g] = rl[j][g] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
           }
@@ -363,7 +369,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
               }
             } else if constexpr (!(ABLE & 1)) {
               __builtin_amdgcn_raw_buffer_store_b128(oh, hi_rsrc, eo, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(ol, lo_rsrc, eo, 0, kResPolicy);
+              if constexpr ((ABL & 2048) != 0) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{ol[0] ^ ol[2], ol[1] ^ ol[3]}, lo_rsrc, eo >> 1, 0, kResPolicy);
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b128(ol, lo_rsrc, eo, 0, kResPolicy);
+              }
             } else {
               asm volatile("" ::"v"(oh), "v"(ol));
             }
@@ -621,7 +632,7 @@ static hipError_t launch_body16w_feat(const ConvParams& p, int epilogue, int abl
     return epilogue == kEpiRelu       ? launch_body16w_one<F / 2, F, kEpiRelu, M>(p, stream, grid_cap)                  \
            : epilogue == kEpiResidual ? launch_body16w_one<F / 2, F, kEpiResidual, M>(p, stream, grid_cap)              \
                                       : launch_body16w_one<F / 2, F, kEpiResidualF32, M>(p, stream, grid_cap);
-  DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31) DSEN2_ABL(32) DSEN2_ABL(96) DSEN2_ABL(128) DSEN2_ABL(256) DSEN2_ABL(512) DSEN2_ABL(1536)
+  DSEN2_ABL(1) DSEN2_ABL(2) DSEN2_ABL(3) DSEN2_ABL(4) DSEN2_ABL(8) DSEN2_ABL(12) DSEN2_ABL(15) DSEN2_ABL(16) DSEN2_ABL(31) DSEN2_ABL(32) DSEN2_ABL(96) DSEN2_ABL(128) DSEN2_ABL(256) DSEN2_ABL(512) DSEN2_ABL(1536) DSEN2_ABL(2048)
 #undef DSEN2_ABL
 #endif
   if (ablate != 0) return hipErrorInvalidValue;
