@@ -214,7 +214,7 @@ int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t coun
 int dsen2_model_workspace_bytes(const dsen2_model* m, int n, int h, int w, size_t* bytes) {
   if (!m || !bytes || n <= 0 || h <= 0 || w <= 0) return fail(DSEN2_ERR_INVALID, "bad argument");
   const size_t pix = (size_t)n * h * w;
-  // fp32: x0 | a | t.   bf16: x0 | a (fp32: first convolution's output, last block's output) | hi | lo | t
+  // fp32: x0 | a | t.   bf16: x0 | a (fp32: the last block's output) | hi | lo | t
   // (hi, lo: the residual stream as two 16-bit planes; t: bf16; each half an fp32 tensor)
   const size_t full = align_up(pix * m->feat), half = align_up(pix * m->feat / 2);
   *bytes = (align_up(pix * 16) + full + (m->precision == 1 ? 3 * half : full)) * sizeof(float);
@@ -266,11 +266,19 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
   const int abl = m->tune.ablate;
   HIP_TRY(launch_pack_inputs(x10, x20, x60, m->c10, m->c20, m->c60, x0, n, h, w, stream));
   size_t li = 0;
+  const bool planes = m->precision == 1 && m->num_layers > 0;
   {
     const Layer& L = m->layers[li++];            // DSen2Net.py:29
-    HIP_TRY(launch_conv3x3(make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f), L.geom, L.epilogue, 0, stream));
+    ConvParams pf = make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f);
+    if (planes) {
+      // a precision-1 model's first convolution writes the residual stream directly as its two blocked 16-bit planes
+      const size_t half = align_up(pix * m->feat / 2);
+      pf.out = t;
+      pf.out2 = t + half;
+    }
+    HIP_TRY(launch_conv3x3(pf, L.geom, planes ? (int)kEpiReluSplit : L.epilogue, 0, stream));
   }
-  if (m->precision == 1 && m->num_layers > 0) {
+  if (planes) {
     // bf16 operands, fp32 accumulate, exact fp32 residual stream held as two 16-bit planes (hi = the bf16 operand of
     // the next convolution, lo = the low halves): conv-A reads hi, conv-B updates (hi, lo) in place; the last
     // block's conv-B writes plain fp32 for the (fp32) output convolution
@@ -278,7 +286,6 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
     void* hi = t;
     void* lo = t + half;
     void* tbf = t + 2 * half;
-    HIP_TRY(launch_split_f32(a, hi, lo, n, h, w, m->feat, stream));
     if (ev_body0) HIP_TRY(hipEventRecord(ev_body0, stream));
     for (int i = 0; i < m->num_layers; ++i) {
       const Layer& LA = m->layers[li++];

@@ -22,6 +22,7 @@
 //     before the MFMAs of the current one and land in LDS after them.
 #include <string.h>
 
+#include "conv3x3_bf16_common.h"
 #include "dsen2_internal.h"
 
 namespace dsen2 {
@@ -249,6 +250,19 @@ __global__ __launch_bounds__(64 * NWAVES, WAVES_PER_SIMD) void conv3x3_mfma_kern
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             *reinterpret_cast<f32x4*>(p.out + pix * COUT + c0) = v;
+          } else if constexpr (EPI == kEpiReluSplit) {
+            // the same values as blocked (hi, lo) planes [n][C/8][h][w][8] (conv3x3_body16w.hip): this lane's 4 channels
+            // are bytes 8*hsel .. 8*hsel+7 of the pixel's 16-byte piece in block c0 >> 3; lanes l and l + 32 complete it
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            const float f0 = v[0], f1 = v[1], f2 = v[2], f3 = v[3];
+            unsigned h01, l01, h23, l23;
+            bf16k::split2(__float_as_uint(f0), __float_as_uint(f1), h01, l01);
+            bf16k::split2(__float_as_uint(f2), __float_as_uint(f3), h23, l23);
+            const size_t off = (((size_t)img * (COUT / 8) + (c0 >> 3)) * img_pix + (size_t)y * p.w + x) * 16 + (c0 & 7) * 2;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) + off) = u32x2{h01, h23};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + off) = u32x2{l01, l23};
           } else if constexpr (EPI == kEpiResidual) {
             const f32x4 res = *reinterpret_cast<const f32x4*>(p.aux + pix * COUT + c0);
 #pragma unroll
@@ -371,6 +385,14 @@ hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogu
   if (geom.variant >= 11 && geom.variant <= 14 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)
     return launch_conv3x3_body32(p, cin_pad, epilogue, geom.variant - 11, ablate, stream);
   if (ablate != 0) return hipErrorInvalidValue;
+  if (cin_pad == 16 && epilogue == kEpiReluSplit) {          // first convolution of a precision-1 model
+    if (!p.out2) return hipErrorInvalidValue;
+#define DSEN2_FIRST(CO, CR) return launch_one<16, 16, CO, 128, kEpiReluSplit, 8, 2, CR>(p, stream);
+    if (cout_pad == 128) { if (geom.variant == 10) DSEN2_FIRST(128, 10) if (geom.variant == 12) DSEN2_FIRST(128, 12) DSEN2_FIRST(128, 0) }
+    if (cout_pad == 256) { if (geom.variant == 10) DSEN2_FIRST(256, 10) if (geom.variant == 12) DSEN2_FIRST(256, 12) DSEN2_FIRST(256, 0) }
+#undef DSEN2_FIRST
+    return hipErrorInvalidValue;
+  }
   if (cin_pad == 16 && epilogue == kEpiRelu && (geom.variant == 10 || geom.variant == 12)) {
     if (cout_pad == 128)
       return geom.variant == 10 ? launch_one<16, 16, 128, 128, kEpiRelu, 8, 2, 10>(p, stream)

@@ -24,7 +24,11 @@ constexpr int kTile = 16;                 // output pixels per workgroup edge (1
 constexpr int kHalo = kTile + 2;          // 18
 constexpr int kHaloPix = kHalo * kHalo;   // 324
 
-enum Epilogue : int { kEpiRelu = 0, kEpiResidual = 1, kEpiSkipNCHW = 2, kEpiResidualF32 = 3 /* bf16 body kernel only */ };
+enum Epilogue : int {
+  kEpiRelu = 0, kEpiResidual = 1, kEpiSkipNCHW = 2,
+  kEpiResidualF32 = 3,   // bf16 body kernel only
+  kEpiReluSplit = 4      // first convolution of a precision-1 model: relu(conv + b) written as blocked (hi, lo) planes (out, out2)
+};
 
 struct ConvParams {
   const float* in;     // NHWC [n][h][w][CIN_PAD]            (bf16 body kernel: bf16 NHWC)
