@@ -1,3 +1,4 @@
+"""What the GPU box gives the CPU baseline: CPU count, affinity, cgroup CPU quota, torch threads, and the oneDNN graph's rate at several thread counts."""
 import os, sys, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 print('nproc', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))

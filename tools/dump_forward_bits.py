@@ -1,3 +1,5 @@
+"""Whole-network outputs of one source tree as an .npz, for bit-for-bit comparison of two trees / libraries in one gpurun call.
+    python tools/dump_forward_bits.py <repo root> <out.npz>"""
 import os, sys, numpy as np, torch
 root = sys.argv[1]; sys.path.insert(0, root)
 from dsen2_amd.DSen2Net import s2model
