@@ -7,8 +7,9 @@ Environment at capture time: numpy 1.26.4, scikit-image 0.18.3, h5py 3.3.0.
 
 The .npz files hold DATA only: seeded integer-valued inputs and the arrays the reference's
 get_test_patches / get_test_patches60 / interp_patches / recompose_images returned for them.
-The real-tile case uses a 264x264 crop of /root/reference/data/S2A_MSIL1C_20170527_T33UUB.mat
-(Copernicus Sentinel data, CC BY 4.0 — see the reference's data/LICENSE.md), stored as uint16.
+The real-tile cases use /root/reference/data/S2A_MSIL1C_20170527_T33UUB.mat (a 264x264 crop, and the whole
+600x600 tile) and S2B_MSIL1C_20171022_T49JGM.mat (whole) — Copernicus Sentinel data, CC BY 4.0, see the
+reference's data/LICENSE.md — stored as uint16.  `make_golden_patches.py bundled` regenerates only the whole tiles.
 """
 import contextlib
 import io
@@ -111,6 +112,45 @@ def case_real_tile(name):
     print(name, p10.shape, q10.shape)
 
 
+BUNDLED = {'tile_T33UUB_600.npz': 'S2A_MSIL1C_20170527_T33UUB.mat',
+           'tile_T49JGM_600.npz': 'S2B_MSIL1C_20171022_T49JGM.mat'}
+SUB = (slice(None), slice(None), slice(3, None, 7), slice(2, None, 5))   # strided subsample of [N, C, H, W]
+
+
+def case_bundled_tile(name, mat):
+    """One of the two tiles the reference ships (data/*.mat, 600x600 @10 m), whole: the arrays themselves (uint16) and
+    what the reference's own tiling / up-sampling / recomposition return for them at the geometry of
+    testing/supres.py:21-22,40-41 — patch counts, per-(patch, band) sums, strided subsamples, the clamped last patch in
+    full, and recompose_images of the up-sampled 20 m patches (row / column sums + a strided subsample)."""
+    import h5py
+    with h5py.File('/root/reference/data/' + mat, 'r') as f:
+        im10 = np.array(f['im10']).transpose()      # testing/demoDSen2.py:14-28 readh5: CHW -> HWC
+        im20 = np.array(f['im20']).transpose()
+        im60 = np.array(f['im60']).transpose()
+    assert im10.shape == (600, 600, 4) and im20.shape == (300, 300, 6) and im60.shape == (100, 100, 2)
+    for a in (im10, im20, im60):
+        assert np.array_equal(a, np.round(a)) and a.min() >= 0 and a.max() < 65536
+    f10, f20, f60 = (a.astype(np.float32) for a in (im10, im20, im60))
+    p10, p20 = get_test_patches(f10, f20, patchSize=128, border=8)
+    q10, q20, q60 = get_test_patches60(f10, f20, f60, patchSize=192, border=12)
+    rec10 = quiet(recompose_images, p10, border=8, size=im10.shape)          # SURVEY §4: == d10 exactly
+    rec10_60 = quiet(recompose_images, q10, border=12, size=im10.shape)
+    assert np.array_equal(rec10, f10) and np.array_equal(rec10_60, f10)
+    rec20 = quiet(recompose_images, p20, border=8, size=im10.shape)          # [600, 600, 6] float32
+    rec60 = quiet(recompose_images, q60, border=12, size=im10.shape)         # [600, 600, 2]
+    sums = lambda a: a.astype(np.float64).sum(axis=(2, 3))
+    np.savez_compressed(
+        os.path.join(HERE, name), source=mat, d10=im10.astype(np.uint16), d20=im20.astype(np.uint16),
+        d60=im60.astype(np.uint16), n20=p10.shape[0], n60=q10.shape[0],
+        p10_sum=sums(p10), p20_sum=sums(p20), p20_sub=p20[SUB], p10_last=p10[-1], p20_last=p20[-1],
+        q10_sum=sums(q10), q20_sum=sums(q20), q60_sum=sums(q60), q20_sub=q20[SUB], q60_sub=q60[SUB],
+        q20_last=q20[-1, :2], q60_last=q60[-1],
+        rec20_rows=rec20.astype(np.float64).sum(axis=1), rec20_cols=rec20.astype(np.float64).sum(axis=0),
+        rec20_sub=rec20[1::5, 2::7], rec60_rows=rec60.astype(np.float64).sum(axis=1),
+        rec60_cols=rec60.astype(np.float64).sum(axis=0), rec60_sub=rec60[1::5, 2::7])
+    print(name, p10.shape, q10.shape, rec20.shape)
+
+
 def case_single_patch(name, rng):
     pred = rng.standard_normal((1, 6, 32, 32)).astype(np.float32)
     rec = quiet(recompose_images, pred, border=4, size=(24, 24, 4))
@@ -119,6 +159,10 @@ def case_single_patch(name, rng):
 
 
 if __name__ == '__main__':
+    if sys.argv[1:] == ['bundled']:          # only the two whole tiles (the other fixtures stay as committed)
+        for name, mat in BUNDLED.items():
+            case_bundled_tile(name, mat)
+        sys.exit(0)
     rng = np.random.default_rng(20170527)
     case20('patches_20_div.npz', rng, 72, 72, 32, 4)        # stride divides: (k+1)^2 alloc, trailing zeros
     case20('patches_20_nondiv.npz', rng, 80, 92, 32, 4)     # clamped last row / column, non-square
@@ -129,3 +173,5 @@ if __name__ == '__main__':
     case_interp('interp.npz', rng)
     case_single_patch('recompose_single.npz', rng)
     case_real_tile('tile_T33UUB_crop.npz')
+    for name, mat in BUNDLED.items():
+        case_bundled_tile(name, mat)

@@ -104,3 +104,21 @@ def test_cli_reads_matlab_v73_tiles(tmp_path):
     with h5py.File(p, 'a') as fh:
         del fh['im60']
     assert cli._load(p)[2] is None
+
+
+REFERENCE_DATA = '/root/reference/data'
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_DATA), reason='the reference checkout is only present in the build container')
+@pytest.mark.parametrize('mat, golden', [('S2A_MSIL1C_20170527_T33UUB.mat', 'tile_T33UUB_600.npz'),
+                                         ('S2B_MSIL1C_20171022_T49JGM.mat', 'tile_T49JGM_600.npz')])
+def test_cli_reads_the_tiles_the_reference_ships(mat, golden):
+    """cli._load on the REAL data/*.mat files (what testing/demoDSen2.py:14-28,42,67 reads) gives the arrays committed
+    in tests/golden/ — which is what every GPU test on the bundled tiles runs on."""
+    from dsen2_amd import cli
+    d10, d20, d60 = cli._load(os.path.join(REFERENCE_DATA, mat))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', golden))
+    assert d10.shape == (600, 600, 4) and d20.shape == (300, 300, 6) and d60.shape == (100, 100, 2)
+    assert str(g['source']) == mat
+    for got, key in ((d10, 'd10'), (d20, 'd20'), (d60, 'd60')):
+        assert np.array_equal(got, g[key].astype(got.dtype)), key

@@ -133,3 +133,36 @@ def test_real_tile_crop_default_geometry(golden_dir):
     # round trip on the real data
     rec = quiet(po.recompose_images, p10, border=8, size=d[0].shape)
     assert np.array_equal(rec, d[0])
+
+
+@pytest.mark.parametrize('name', ['tile_T33UUB_600.npz', 'tile_T49JGM_600.npz'])
+def test_whole_bundled_tiles(golden_dir, name):
+    """The two tiles the reference ships, whole (600x600 @10 m): 36 / 16 patches, sums, subsamples, the
+    clamped last patch, and recompose_images of the up-sampled patches — all as captured from utils/patches.py."""
+    g = load(golden_dir, name)
+    d = [g[k].astype(np.float32) for k in ('d10', 'd20', 'd60')]
+    assert d[0].shape == (600, 600, 4) and d[1].shape == (300, 300, 6) and d[2].shape == (100, 100, 2)
+    sub = (slice(None), slice(None), slice(3, None, 7), slice(2, None, 5))
+    sums = lambda a: a.astype(np.float64).sum(axis=(2, 3))
+    p10, p20 = po.get_test_patches(d[0], d[1], patchSize=128, border=8, f32_coords=True)
+    assert p10.shape[0] == int(g['n20']) == 36
+    np.testing.assert_array_equal(sums(p10), g['p10_sum'])
+    assert np.array_equal(p10[-1], g['p10_last'])
+    np.testing.assert_allclose(p20[sub], g['p20_sub'], **TIGHT)
+    np.testing.assert_allclose(p20[-1], g['p20_last'], **TIGHT)
+    np.testing.assert_allclose(sums(p20), g['p20_sum'], rtol=1e-6)
+    q10, q20, q60 = po.get_test_patches60(*d, patchSize=192, border=12, f32_coords=True)
+    assert q10.shape[0] == int(g['n60']) == 16
+    np.testing.assert_array_equal(sums(q10), g['q10_sum'])
+    np.testing.assert_allclose(q20[sub], g['q20_sub'], **TIGHT)
+    np.testing.assert_allclose(q60[sub], g['q60_sub'], **TIGHT)
+    np.testing.assert_allclose(q20[-1, :2], g['q20_last'], **TIGHT)
+    np.testing.assert_allclose(q60[-1], g['q60_last'], **TIGHT)
+    assert np.array_equal(quiet(po.recompose_images, p10, border=8, size=d[0].shape), d[0])
+    assert np.array_equal(quiet(po.recompose_images, q10, border=12, size=d[0].shape), d[0])
+    rec20 = quiet(po.recompose_images, p20, border=8, size=d[0].shape)
+    np.testing.assert_allclose(rec20[1::5, 2::7], g['rec20_sub'], **TIGHT)
+    np.testing.assert_allclose(rec20.astype(np.float64).sum(axis=1), g['rec20_rows'], rtol=1e-6)
+    rec60 = quiet(po.recompose_images, q60, border=12, size=d[0].shape)
+    np.testing.assert_allclose(rec60[1::5, 2::7], g['rec60_sub'], **TIGHT)
+    np.testing.assert_allclose(rec60.astype(np.float64).sum(axis=0), g['rec60_cols'], rtol=1e-6)
