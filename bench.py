@@ -21,8 +21,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# RCCL between processes needs dmabuf IPC on this driver stack; must be in the environment before HIP initialises
-os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 H = W = 32
 # BASELINE.json configs.  The default (what the driver runs) is configs[1]; the others are for our own runs.
@@ -76,23 +74,15 @@ def main():
     from dsen2_amd import weights as dweights
     from dsen2_amd.DSen2Net import s2model
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    rank, local_rank, world = ddist.launched_world()
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; launch N>1 with torch.distributed.run\n'
                              % (args.gpus, world))
         sys.exit(2)
-    dev_index = local_rank if args.backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    dev = torch.device('cuda', dev_index)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.backend == 'nccl':
-            td.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            td.init_process_group('gloo', rank=rank, world_size=world)
+    # one process per GPU: this rank's device (LOCAL_RANK), the dmabuf-IPC environment RCCL needs (set before HIP
+    # initialises) and the process group — the same entry the drop-in CLI uses (dsen2_amd/dist.py)
+    rank, world, dev = ddist.init_from_env(args.backend)
 
     # ---- setup (untimed): weights on rank 0 -> RCCL broadcast; synthetic inputs in HBM ----
     n_params = dweights.num_params(sum(BANDS), BANDS[-1], NUM_LAYERS, FEAT)
@@ -221,9 +211,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        td.barrier()
-        td.destroy_process_group()
+    ddist.finalize()
 
 
 if __name__ == '__main__':

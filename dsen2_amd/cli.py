@@ -2,7 +2,14 @@
 
     python -m dsen2_amd.cli INPUT [OUTPUT] [--run_60] [--copy_original_bands] [--roi_x_y x1,y1,x2,y2]
                                   [--output_file_format GTiff|ENVI|...|npz] [--select_UTM ZONE] [--save_prefix P]
+                                  [--roi_lon_lat lon1,lat1,lon2,lat2] [--list_bands] [--list_UTM]
+                                  [--list_output_file_formats]
                                   [--bands10 B4,B3,B2,B8] [--models DIR] [--precision fp32|bf16] [--deep]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m dsen2_amd.cli INPUT [OUTPUT] ...                       one process per GPU: the patches of the tile are
+        sharded over the ranks (dsen2_amd/dist.py: RCCL over xGMI), rank 0 receives the predictions, recomposes
+        and is the only rank that prints or writes.  Every rank opens INPUT itself and holds the whole host arrays
+        (2.7 GB as uint16 for a 10980^2 product) but uploads only the rows its patches read.
 
 Two kinds of INPUT:
   * an array file — .npz with keys data10 [x,y,4], data20 [x/2,y/2,6], data60 [x/6,y/6,2] (aliases d10/d20/d60),
@@ -65,6 +72,38 @@ def snap_roi(x1, y1, x2, y2, width, height):
     return int(xmin / 6) * 6, int(ymin / 6) * 6, int((xmax + 1) / 6) * 6 - 1, int((ymax + 1) / 6) * 6 - 1
 
 
+def lon_lat_to_pixel(ds, osr, lon, lat):
+    """s2_tiles_supres.py:141-163 — WGS84 (lon, lat) -> (x, y) pixel of a geo-referenced dataset: transform into the
+    dataset's projection, subtract the origin, apply the inverse of the geo-transform's 2x2 matrix."""
+    x0, ax, bx, y0, ay, by = ds.GetGeoTransform()
+    proj = osr.SpatialReference()
+    proj.ImportFromWkt(ds.GetProjection())
+    wgs = osr.SpatialReference()
+    wgs.SetWellKnownGeogCS('WGS84')
+    px, py, _ = osr.CoordinateTransformation(wgs, proj).TransformPoint(lon, lat, 0.)
+    px, py = px - x0, py - y0
+    det = ax * by - ay * bx
+    return int((by * px - bx * py) / det), int((-ay * px + ax * py) / det)
+
+
+def creatable_raster_formats(gdal):
+    """s2_tiles_supres.py:64-80 (--list_output_file_formats): 'NAME: long name (extensions)' of every GDAL driver
+    that can create raster files."""
+    lines = []
+    for i in range(gdal.GetDriverCount()):
+        driver = gdal.GetDriver(i)
+        meta = driver.GetMetadata() if driver else None
+        if not meta or meta.get(gdal.DCAP_CREATE) != 'YES' or meta.get(gdal.DCAP_RASTER) != 'YES':
+            continue
+        line = driver.GetDescription()
+        if 'DMD_LONGNAME' in meta:
+            line += ': ' + meta['DMD_LONGNAME']
+        if 'DMD_EXTENSIONS' in meta:
+            line += ' (' + meta['DMD_EXTENSIONS'] + ')'
+        lines.append(line)
+    return lines
+
+
 def short_band_name(description):
     """s2_tiles_supres.py:243-248 — 'B4, central wavelength 665 nm' -> 'B4'."""
     for sep in (',', ' '):
@@ -87,8 +126,10 @@ def tidy_description(description, fmt):
 class GdalProduct(object):
     """The GDAL side of s2_tiles_supres.py for one product: which sub-datasets and bands, the ROI, the arrays."""
 
-    def __init__(self, gdal, path, want, roi_x_y=None, select_utm='', fmt='GTiff'):
+    def __init__(self, gdal, path, want, roi_x_y=None, select_utm='', fmt='GTiff', roi_lon_lat=None, osr=None):
         self.gdal, self.fmt = gdal, fmt
+        if roi_lon_lat and not roi_x_y and osr is None:
+            raise ImportError('--roi_lon_lat needs osgeo.osr')
         raster = gdal.Open(path)
         if raster is None:
             raise OSError('GDAL cannot open %r' % path)
@@ -101,20 +142,30 @@ class GdalProduct(object):
             raise ValueError('no 10 m / 20 m sub-dataset in %r' % path)
         # several UTM zones in one product: the requested one, else the one whose ROI covers most pixels (:102-187)
         best = None
+        self.coverage = {}                         # UTM zone -> ROI coverage in 10 m pixels (--list_UTM, :173-176,189-193)
         for idx, (name, desc) in enumerate(tens):
             ds = gdal.Open(name)
             w, h = ds.RasterXSize, ds.RasterYSize
-            box = snap_roi(roi_x_y[0], roi_x_y[1], roi_x_y[2], roi_x_y[3], w, h) if roi_x_y else (0, 0, w - 1, h - 1)
+            if roi_x_y:                            # pixels win over lon/lat when both are given (:125-137)
+                box = snap_roi(roi_x_y[0], roi_x_y[1], roi_x_y[2], roi_x_y[3], w, h)
+            elif roi_lon_lat:
+                xa, ya = lon_lat_to_pixel(ds, osr, roi_lon_lat[0], roi_lon_lat[1])
+                xb, yb = lon_lat_to_pixel(ds, osr, roi_lon_lat[2], roi_lon_lat[3])
+                box = snap_roi(xa, ya, xb, yb, w, h)
+            else:
+                box = (0, 0, w - 1, h - 1)
             utm = desc[desc.find('UTM'):] if 'UTM' in desc else ''
             area = (box[2] - box[0] + 1) * (box[3] - box[1] + 1)
+            self.coverage[utm] = max(area, self.coverage.get(utm, 0))
             if select_utm and utm == select_utm:
                 best = (area, idx, box, utm)
                 break
             if best is None or area > best[0]:
                 best = (area, idx, box, utm)
         _, idx, (self.xmin, self.ymin, self.xmax, self.ymax), self.utm = best
-        if self.xmax < self.xmin or self.ymax < self.ymin:
-            raise ValueError('Invalid region of interest / UTM Zone combination')
+        self.valid = self.xmax >= self.xmin and self.ymax >= self.ymin
+        if not self.valid:                         # main() prints the reference's message and exits 0 (:196-198)
+            return
 
         def same_zone(cands):
             hit = [c for c in cands if self.utm and self.utm in c[1]]
@@ -136,6 +187,16 @@ class GdalProduct(object):
                     self.names[key].append(sn)
                     self.index[key].append(b)
                     self.descriptions[sn] = desc
+
+    def band_listing(self):
+        """--list_bands (s2_tiles_supres.py:229-239): every band of the three selected sub-datasets."""
+        lines = []
+        for key in ('10m', '20m', '60m'):
+            lines += ['', '%s bands:' % key]
+            ds = self.ds[key]
+            lines += ['- ' + tidy_description(ds.GetRasterBand(b + 1).GetDescription(), self.fmt)
+                      for b in range(ds.RasterCount if ds is not None else 0)]
+        return lines + ['']
 
     def read(self, key):
         """HWC array of the selected bands of one resolution, ROI applied (:311-329)."""
@@ -169,9 +230,13 @@ class GdalProduct(object):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description='Perform super-resolution on Sentinel-2 with DSen2 on MI355X.')
-    ap.add_argument('data_file')
+    ap.add_argument('data_file', nargs='?')
     ap.add_argument('output_file', nargs='?')
     ap.add_argument('--roi_x_y', default='', help='x_1,y_1,x_2,y_2 on the 10m bands; extended to 60m pixel boundaries')
+    ap.add_argument('--roi_lon_lat', default='', help='GDAL input: lon_1,lat_1,lon_2,lat_2 (WGS84, decimal); needs osgeo.osr')
+    ap.add_argument('--list_bands', action='store_true', help='GDAL input: list the bands of the selected UTM zone and exit')
+    ap.add_argument('--list_UTM', action='store_true', help='GDAL input: list the UTM zones with their ROI coverage and exit')
+    ap.add_argument('--list_output_file_formats', action='store_true', help='list the raster formats GDAL can create and exit')
     ap.add_argument('--run_60', action='store_true', help='also super-resolve the 60m bands (B1,B9)')
     ap.add_argument('--copy_original_bands', action='store_true')
     ap.add_argument('--save_prefix', default='')
@@ -182,8 +247,43 @@ def main(argv=None):
     ap.add_argument('--models', default=None, help='directory with the checkpoints (default: supres.MDL_PATH)')
     ap.add_argument('--deep', action='store_true', help='VDSen2 (d=32, F=256)')
     ap.add_argument('--precision', default=None, choices=['fp32', 'bf16'])
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='under torch.distributed.run: nccl = RCCL, one GPU per rank; gloo = rehearsal with shared GPUs')
     args = ap.parse_args(argv)
 
+    if args.list_output_file_formats:                              # s2_tiles_supres.py:64-80: before anything is opened
+        try:
+            from osgeo import gdal
+        except ImportError:
+            print('GDAL (osgeo) is not importable: the only output format is npz')
+            return 2
+        for line in creatable_raster_formats(gdal):
+            print(line)
+        return 0
+    if not args.data_file:
+        ap.error('the following arguments are required: data_file')
+
+    # One process per GPU under torch.distributed.run: only rank 0 talks and writes.  The process group is entered
+    # before the first HIP call (dist.init_from_env) and left on every way out.
+    from . import dist
+    rank, _, world = dist.launched_world()
+    keep_stdout = sys.stdout
+    try:
+        if rank != 0:
+            sys.stdout = open(os.devnull, 'w')
+        if world > 1:
+            dist.init_from_env(args.backend)
+        rc = _run(args)
+        if world > 1:
+            dist.finalize()                # barrier, then leave the group (a rank that raised skips the barrier:
+        return rc                          # torch.distributed.run then ends its peers)
+    finally:
+        if sys.stdout is not keep_stdout:
+            sys.stdout.close()
+            sys.stdout = keep_stdout
+
+
+def _run(args):
     from . import supres
     if args.models:
         supres.MDL_PATH = os.path.join(args.models, '')
@@ -207,8 +307,19 @@ def main(argv=None):
             raise ValueError('%d names for %d 10 m channels' % (len(names10), data10.shape[2]))
         names10, names20, names60 = names10[:data10.shape[2]], list(BANDS20), list(BANDS60)
         descriptions = dict((b, b) for b in names10 + names20 + names60)
+        if args.roi_lon_lat or args.list_bands or args.list_UTM or args.select_UTM:
+            print('--roi_lon_lat / --list_bands / --list_UTM / --select_UTM need a geo-referenced product; '
+                  '%s is an array file' % args.data_file)
+            return 2
+        if args.output_file_format not in (None, 'npz'):
+            print('array input carries no geo-reference: --output_file_format %s is ignored, writing npz'
+                  % args.output_file_format)
         if roi:
             xmin, ymin, xmax, ymax = snap_roi(roi[0], roi[1], roi[2], roi[3], data10.shape[1], data10.shape[0])
+            print('Selected pixel region: xmin=%d, ymin=%d, xmax=%d, ymax=%d:' % (xmin, ymin, xmax, ymax))
+            if xmax < xmin or ymax < ymin:                         # smaller than one 60 m cell (s2_tiles_supres.py:196-198)
+                print('Invalid region of interest / UTM Zone combination')
+                return 0
             data10 = data10[ymin:ymax + 1, xmin:xmax + 1]
             data20 = data20[ymin // 2:(ymax + 1) // 2, xmin // 2:(xmax + 1) // 2]
             if data60 is not None:
@@ -223,15 +334,36 @@ def main(argv=None):
                   '.npz (keys data10, data20, data60), or run the reference script with the supres shim of '
                   'INTEGRATION.md' % args.data_file)
             return 2
+        try:
+            from osgeo import osr
+        except ImportError:
+            osr = None
         fmt = args.output_file_format or 'GTiff'
+        lon_lat = [float(v) for v in re.split(',', args.roi_lon_lat)] if args.roi_lon_lat else None
         want = 'B1,B2,B3,B4,B5,B6,B7,B8,B8A,B9,B11,B12' if args.run_60 else 'B2,B3,B4,B5,B6,B7,B8,B8A,B11,B12'
         try:
-            product = GdalProduct(gdal, args.data_file, want.split(','), roi, args.select_UTM, fmt)
-        except ValueError as e:
+            product = GdalProduct(gdal, args.data_file, want.split(','), roi, args.select_UTM, fmt, lon_lat, osr)
+        except (ValueError, ImportError) as e:
             print(e)
-            return 0                                               # the reference exits 0 here too (:196-198)
+            return 2
+        if args.list_UTM:                                          # :189-193
+            print('List of UTM zones (with ROI coverage in pixels):')
+            for zone, area in product.coverage.items():
+                print('%s (%d)' % (zone, area))
+            return 0
         print('Selected UTM Zone:', product.utm)
         print('Selected pixel region: xmin=%d, ymin=%d, xmax=%d, ymax=%d:' % (product.xmin, product.ymin, product.xmax, product.ymax))
+        print('Image size: width=%d x height=%d' % (product.xmax - product.xmin + 1, product.ymax - product.ymin + 1))
+        if not product.valid:
+            print('Invalid region of interest / UTM Zone combination')
+            return 0                                               # the reference exits 0 here too (:196-198)
+        if args.list_bands:                                        # :229-239, then the selection lines, then exit (:295-296)
+            for line in product.band_listing():
+                print(line)
+        for key in ('10m', '20m', '60m'):
+            print('Selected %s bands: %s' % (key, ' '.join(product.names[key])))
+        if args.list_bands:
+            return 0
         data10, data20, data60 = product.read('10m'), product.read('20m'), product.read('60m')
         names10, names20, names60 = product.names['10m'], product.names['20m'], product.names['60m']
         descriptions = product.descriptions

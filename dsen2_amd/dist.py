@@ -10,9 +10,64 @@ Partitioning: contiguous ranges of the row-major patch index, ceil(N/R) per rank
 short or empty).  With backend "nccl" (= RCCL on ROCm) tensors stay on the GPU; with "gloo" (CPU tests)
 they are staged through host memory.
 """
+import os
+import sys
+
 import numpy as np
 import torch
 import torch.distributed as td
+
+BACKENDS = ('nccl', 'gloo')
+
+
+def launched_world():
+    """(rank, local_rank, world) of a `python -m torch.distributed.run` launch (RANK / LOCAL_RANK / WORLD_SIZE in the
+    environment); (0, 0, 1) for a plain `python` start."""
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
+            int(os.environ.get('WORLD_SIZE', '1')))
+
+
+def init_from_env(backend='nccl'):
+    """The N-GPU entry of every front end (dsen2_amd.cli, bench.py, tools/bench_full_tile.py): one process per GPU,
+    launched by torch.distributed.run.  Selects this rank's GPU (LOCAL_RANK) and, when WORLD_SIZE > 1, initialises
+    torch.distributed — backend 'nccl' = RCCL over xGMI; 'gloo' is a rehearsal of the control flow on a box with fewer
+    GPUs than ranks (ranks share devices, collectives are staged through host memory).  Returns (rank, world, device).
+
+    Must run before anything initialises HIP: RCCL's intra-node transport exchanges buffer handles between the rank
+    processes, and this driver stack only supports the dmabuf form of that (HSA_ENABLE_IPC_MODE_LEGACY=0; with the
+    legacy mode hipIpcGetMemHandle fails with "invalid argument").  The runtime reads the variable once, when it
+    starts, so it is set here — not by the user, not at import time — and only for a multi-process run."""
+    if backend not in BACKENDS:
+        raise ValueError('backend %r (one of %s)' % (backend, ', '.join(BACKENDS)))
+    rank, local_rank, world = launched_world()
+    if world > 1:
+        if 'HSA_ENABLE_IPC_MODE_LEGACY' not in os.environ:
+            if torch.cuda.is_initialized():
+                sys.stderr.write('dsen2_amd.dist: HIP was initialised before init_from_env(); '
+                                 'HSA_ENABLE_IPC_MODE_LEGACY=0 can no longer take effect\n')
+            os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    n_dev = torch.cuda.device_count()            # counting devices does not initialise HIP
+    if n_dev == 0:
+        raise RuntimeError('dsen2_amd needs a ROCm GPU (gfx950); there is no CPU fallback')
+    if backend == 'nccl' and local_rank >= n_dev:
+        raise RuntimeError('LOCAL_RANK %d but %d GPU(s) visible: RCCL needs one GPU per rank '
+                           '(backend gloo rehearses with shared devices)' % (local_rank, n_dev))
+    dev = torch.device('cuda', local_rank % n_dev)
+    torch.cuda.set_device(dev)
+    if world > 1 and not td.is_initialized():
+        if backend == 'nccl':
+            td.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            td.init_process_group('gloo', rank=rank, world_size=world)
+    return rank, world, dev
+
+
+def finalize():
+    """Leave the process group (if any) after a last barrier, so no rank tears RCCL down under a peer's collective."""
+    if td.is_available() and td.is_initialized():
+        td.barrier()
+        td.destroy_process_group()
 
 
 def rank_world():

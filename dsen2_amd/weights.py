@@ -61,22 +61,31 @@ def _from_keras_hdf5(path, shapes):
             bias = [n for n in wn if n.split('/')[-1].startswith('bias')]
             if len(wn) != 2 or len(kern) != 1 or len(bias) != 1:
                 raise ValueError('%s: layer %r holds weights %r, expected one kernel and one bias' % (path, lname, wn))
-            for n in wn:
-                if n.split('/')[0] != lname:
-                    raise ValueError('%s: weight %r does not belong to layer %r' % (path, n, lname))
+            # (the weight's own path is what is read: a name scope TensorFlow made unique — 'conv2d_1_1/kernel:0' under
+            # layer 'conv2d_1' — is legitimate)
             m = re.search(r'(\d+)$', lname)
-            convs.append((int(m.group(1)) if m else len(convs), lname, np.asarray(grp[kern[0]]), np.asarray(grp[bias[0]])))
-        # Graph order (utils/DSen2Net.py:29-35) is the order the Conv2D layers were created = their numeric suffix
-        # (conv2d_7, conv2d_8, ... when other models were built in the same session); the attribute order of an HDF5
-        # file is not something to rely on
-        convs.sort(key=lambda c: c[0])
-        if len(set(c[0] for c in convs)) != len(convs):
-            raise ValueError('%s: conv layer names %r have no unique numeric order' % (path, [c[1] for c in convs]))
+            # multi-backend keras numbers from conv2d_1; tf.keras calls the session's first layer plain 'conv2d'
+            convs.append((int(m.group(1)) if m else 0, lname, np.asarray(grp[kern[0]]), np.asarray(grp[bias[0]])))
         if len(convs) != len(shapes):
             raise ValueError('%s holds %d conv layers, the architecture has %d' % (path, len(convs), len(shapes)))
-        for (_, lname, k, b), (a, o) in zip(convs, shapes):
-            if k.shape != (3, 3, a, o) or b.shape != (o,):
-                raise ValueError('layer %s: shape %s/%s does not match (3,3,%d,%d)' % (lname, k.shape, b.shape, a, o))
+
+        def mismatch(order):
+            for (_, lname, k, b), (a, o) in zip(order, shapes):
+                if k.shape != (3, 3, a, o) or b.shape != (o,):
+                    return 'layer %s: shape %s/%s does not match (3,3,%d,%d)' % (lname, k.shape, b.shape, a, o)
+            return None
+        # Graph order (utils/DSen2Net.py:29-35) is the order the Conv2D layers were created = their numeric suffix
+        # (conv2d_7, conv2d_8, ... when other models were built in the same session).  Names without a usable
+        # numbering (missing or repeated suffixes) fall back to the file's layer_names order.  Either way the order
+        # must chain: Cin of the first layer, F -> F through the body, Cout of the last.
+        orders = []
+        if len(set(c[0] for c in convs)) == len(convs):
+            orders.append(sorted(convs, key=lambda c: c[0]))
+        orders.append(convs)
+        errors = [mismatch(o) for o in orders]
+        if all(errors):
+            raise ValueError('%s: %s' % (path, errors[0]))
+        for _, _, k, b in orders[errors.index(None)]:
             parts += [k.astype(np.float32).ravel(), b.astype(np.float32)]
     return np.concatenate(parts)
 

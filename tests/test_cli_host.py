@@ -139,11 +139,48 @@ def _fake_gdal(d10, d20, d60, can_create=True):
         def Create(self, path, w, h, n, dtype):
             created[path] = _Dataset([np.zeros((h, w)) for _ in range(n)], [''] * n)
             return created[path]
-    gdal.DCAP_CREATE, gdal.GDT_Float64 = 'DCAP_CREATE', 7
+    class ListedDriver(object):
+        def __init__(self, name, meta):
+            self.name, self.meta = name, meta
+
+        def GetMetadata(self):
+            return self.meta
+
+        def GetDescription(self):
+            return self.name
+    gdal.DCAP_CREATE, gdal.DCAP_RASTER, gdal.GDT_Float64 = 'DCAP_CREATE', 'DCAP_RASTER', 7
+    listed = [ListedDriver('GTiff', {'DCAP_CREATE': 'YES', 'DCAP_RASTER': 'YES', 'DMD_LONGNAME': 'GeoTIFF', 'DMD_EXTENSIONS': 'tif tiff'}),
+              ListedDriver('ENVI', {'DCAP_CREATE': 'YES', 'DCAP_RASTER': 'YES', 'DMD_LONGNAME': 'ENVI .hdr Labelled'}),
+              ListedDriver('JP2ECW', {'DCAP_RASTER': 'YES', 'DMD_LONGNAME': 'read only'}),
+              ListedDriver('GPKG', {'DCAP_CREATE': 'YES', 'DMD_LONGNAME': 'vector only'}), None]
+    gdal.GetDriverCount = lambda: len(listed)
+    gdal.GetDriver = lambda i: listed[i]
     gdal.Open = lambda name: store.get(os.path.basename(name))
     gdal.GetDriverByName = lambda fmt: Driver() if fmt in ('GTiff', 'ENVI', 'PCIDSK') else None
     gdal.created = created
     return gdal
+
+
+def _fake_osr():
+    """osgeo.osr stand-in whose "projection" is UTM-like metres = 600000 + 1000 * lon, 5000000 + 1000 * (lat - 45):
+    enough to check the geo-transform inversion of s2_tiles_supres.py:141-163."""
+    osr = types.ModuleType('osgeo.osr')
+
+    class SpatialReference(object):
+        def ImportFromWkt(self, wkt):
+            self.wkt = wkt
+
+        def SetWellKnownGeogCS(self, name):
+            self.wkt = name
+
+    class CoordinateTransformation(object):
+        def __init__(self, src, dst):
+            assert src.wkt == 'WGS84' and dst.wkt.startswith('PROJCS')
+
+        def TransformPoint(self, lon, lat, h):
+            return 600000.0 + 1000.0 * lon, 5000000.0 + 1000.0 * (lat - 45.0), h
+    osr.SpatialReference, osr.CoordinateTransformation = SpatialReference, CoordinateTransformation
+    return osr
 
 
 @pytest.fixture
@@ -151,9 +188,10 @@ def with_gdal(monkeypatch):
     def install(d10, d20, d60, **kw):
         gdal = _fake_gdal(d10, d20, d60, **kw)
         osgeo = types.ModuleType('osgeo')
-        osgeo.gdal = gdal
+        osgeo.gdal, osgeo.osr = gdal, _fake_osr()
         monkeypatch.setitem(sys.modules, 'osgeo', osgeo)
         monkeypatch.setitem(sys.modules, 'osgeo.gdal', gdal)
+        monkeypatch.setitem(sys.modules, 'osgeo.osr', osgeo.osr)
         return gdal
     return install
 
@@ -195,3 +233,49 @@ def test_gdal_branch_falls_back_to_npz_and_without_gdal_says_so(fake_supres, wit
     monkeypatch.setitem(sys.modules, 'osgeo', None)                                     # import osgeo -> ImportError
     assert cli.main(['S2A.zip', out]) == 2
     assert 'GDAL (osgeo) is not importable' in capsys.readouterr().out
+
+
+def test_gdal_listing_options_and_lon_lat_roi(fake_supres, with_gdal, tmp_path, capsys):
+    """--list_output_file_formats (s2_tiles_supres.py:64-80), --list_UTM (:189-193), --list_bands (:229-239,295-296)
+    and --roi_lon_lat (:141-170): query options print and exit without an output file; the lon/lat box goes through
+    the dataset's projection and the inverse geo-transform, then to 60 m boundaries like a pixel box."""
+    from dsen2_amd import cli
+    d10, d20, d60 = _arrays(48)
+    gdal = with_gdal(d10, d20, d60)
+    assert cli.main(['--list_output_file_formats']) == 0
+    assert capsys.readouterr().out.splitlines() == ['GTiff: GeoTIFF (tif tiff)', 'ENVI: ENVI .hdr Labelled']
+    assert cli.main(['S2A.zip', '--list_UTM', '--roi_x_y', '13,7,40,30']) == 0
+    assert capsys.readouterr().out.splitlines() == ['List of UTM zones (with ROI coverage in pixels):', 'UTM 33N (576)']
+    assert cli.main(['S2A.zip', '--list_bands', '--run_60']) == 0
+    printed = capsys.readouterr().out
+    assert '\n10m bands:\n- B4 (665 nm)\n- B3 (560 nm)' in printed and '\n60m bands:\n- B1 (443 nm)\n- B9 (945 nm)\n- B10 (1375 nm)\n' in printed
+    assert 'Selected 10m bands: B4 B3 B2 B8' in printed and 'Selected 60m bands: B1 B9' in printed
+    assert not gdal.created                                        # nothing was super-resolved or written
+    # geo-transform (600000, 10, 0, 5000000, 0, -10): x = 100 * lon, y = -100 * (lat - 45)
+    out = str(tmp_path / 'll.tif')
+    assert cli.main(['S2A.zip', out, '--roi_lon_lat', '0.13,44.93,0.40,44.70']) == 0
+    assert 'Selected pixel region: xmin=12, ymin=6, xmax=35, ymax=29' in capsys.readouterr().out
+    assert gdal.created[out].data[0].shape == (24, 24)
+    assert np.array_equal(gdal.created[out].data[0], np.repeat(np.repeat(d20[3:15, 6:18, 0], 2, 0), 2, 1))
+    # a region smaller than one 60 m cell: the reference's message, exit 0, nothing written
+    out2 = str(tmp_path / 'tiny.tif')
+    assert cli.main(['S2A.zip', out2, '--roi_x_y', '13,13,15,15']) == 0
+    assert 'Invalid region of interest / UTM Zone combination' in capsys.readouterr().out and out2 not in gdal.created
+
+
+def test_array_input_validates_the_roi_and_says_what_it_ignores(fake_supres, tmp_path, capsys):
+    """an ROI smaller than one 60 m cell prints the reference's message and exits 0 (s2_tiles_supres.py:196-198)
+    instead of failing inside the tiling; a GDAL format / geo option on an array file is reported, not silently dropped."""
+    from dsen2_amd import cli
+    d10, d20, d60 = _arrays(48)
+    inp = str(tmp_path / 'tile.npz')
+    np.savez(inp, data10=d10, data20=d20, data60=d60[:, :, :2])
+    out = str(tmp_path / 'o.npz')
+    assert cli.main([inp, out, '--roi_x_y', '13,13,15,15']) == 0
+    assert 'Invalid region of interest' in capsys.readouterr().out and not os.path.exists(out)
+    assert cli.main([inp, out, '--output_file_format', 'GTiff']) == 0
+    assert '--output_file_format GTiff is ignored, writing npz' in capsys.readouterr().out and os.path.exists(out)
+    assert cli.main([inp, out, '--list_bands']) == 2
+    assert 'need a geo-referenced product' in capsys.readouterr().out
+    with pytest.raises(SystemExit):
+        cli.main([])

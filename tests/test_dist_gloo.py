@@ -77,3 +77,20 @@ def test_broadcast_and_gather_to_root(world, total):
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(world))
     assert res == {r: True for r in range(world)}
+
+
+def test_launch_environment_is_read_like_torch_distributed_run_sets_it(monkeypatch):
+    """dist.launched_world(): RANK / LOCAL_RANK / WORLD_SIZE of a torch.distributed.run launch; a plain start is
+    (0, 0, 1).  init_from_env() refuses an unknown backend before touching any device."""
+    from dsen2_amd import dist
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        monkeypatch.delenv(k, raising=False)
+    assert dist.launched_world() == (0, 0, 1)
+    monkeypatch.setenv('RANK', '5'); monkeypatch.setenv('LOCAL_RANK', '1'); monkeypatch.setenv('WORLD_SIZE', '8')
+    assert dist.launched_world() == (5, 1, 8)
+    with pytest.raises(ValueError):
+        dist.init_from_env('mpi')
+    if not torch.cuda.is_available():               # the product has no CPU fallback: the N-GPU entry says so
+        monkeypatch.setenv('WORLD_SIZE', '1')
+        with pytest.raises(RuntimeError):
+            dist.init_from_env('gloo')

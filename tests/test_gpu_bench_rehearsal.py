@@ -102,3 +102,37 @@ def test_rccl_initialises_and_runs_the_bench_collectives_on_one_rank():
                HSA_ENABLE_IPC_MODE_LEGACY='0')
     p = subprocess.run([sys.executable, '-c', _RCCL_ONE_RANK], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode == 0 and 'rccl one rank ok' in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
+def test_cli_two_ranks_gloo_writes_the_single_rank_file_from_rank_0_only(tmp_path):
+    """The drop-in CLI under torch.distributed.run (the stand-in for testing/s2_tiles_supres.py:332-342,371-420 on N
+    GPUs): `python -m torch.distributed.run ... -m dsen2_amd.cli tile.npz out.npz` with 2 ranks (gloo rehearsal, both on
+    the one GPU) enters the process group itself, shards the patches, and rank 0 alone prints and writes — the same
+    bytes per band as the single-process run."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from dsen2_amd import weights
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'tile_T33UUB_crop.npz'))
+    inp = str(tmp_path / 'tile.npz')
+    np.savez(inp, data10=g['d10'], data20=g['d20'], data60=g['d60'])
+    mdl = tmp_path / 'models'
+    mdl.mkdir()
+    np.save(str(mdl / 's2_032_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 6, 128, seed=11))
+    np.save(str(mdl / 's2_030_lr_1e-05.npy'), weights.random_he_uniform(12, 2, 6, 128, seed=12))
+    common = ['--run_60', '--copy_original_bands', '--models', str(mdl)]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    single = subprocess.run([sys.executable, '-m', 'dsen2_amd.cli', inp, str(tmp_path / 'one.npz')] + common,
+                            capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert single.returncode == 0, single.stderr[-2000:]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', _free_port(), '-m', 'dsen2_amd.cli', inp, str(tmp_path / 'two.npz'), '--backend', 'gloo'] + common
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    # one rank talked: every line of the single-process run appears exactly once
+    assert p.stdout.count('Writing the original 10m bands and the super-resolved bands') == 1
+    assert p.stdout.count('Super-resolving the 20m data into 10m bands') == 1
+    one = np.load(str(tmp_path / 'one.npz'), allow_pickle=True)['bands'].item()
+    two = np.load(str(tmp_path / 'two.npz'), allow_pickle=True)['bands'].item()
+    assert list(one) == list(two) and len(one) == 12
+    for k in one:
+        assert np.array_equal(one[k], two[k]), k

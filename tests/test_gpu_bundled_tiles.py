@@ -85,50 +85,36 @@ def test_tiling_of_the_whole_bundled_tile_equals_the_reference_capture(golden_di
     np.testing.assert_allclose(rec60.astype(np.float64).sum(axis=0), g['rec60_cols'], rtol=1e-6)
 
 
-def oracle_image(p, flat, cout, patch, border, size, keep):
-    """Oracle pipeline on the patches listed in `keep` (all when None): the others stay NaN, and so do the pixels of
-    the image that only they write (recompose_images: later tiles overwrite earlier ones, patches.py:394-403)."""
+def oracle_image(p, flat, cout, patch, border, size):
+    """Oracle pipeline: /2000, float64 C oracle CNN on every patch, oracle recomposition, *2000 (testing/supres.py:23-29)."""
     p = [a / np.float32(2000) for a in p]
-    n = p[0].shape[0]
-    keep = list(range(n)) if keep is None else list(keep)
-    pred = np.full((n, cout, patch, patch), np.nan)
-    pred[keep] = c_oracle.forward([a[keep] for a in p], flat, 6, 128)
+    pred = c_oracle.forward(p, flat, 6, 128)
     return quiet(po.recompose_images, pred, border=border, size=size).astype(np.float64) * 2000
-
-
-# T33UUB: every patch through the float64 oracle.  T49JGM: a third of them — first, interior, and the clamped last
-# row / column (6 x 6 grid at 20 m: indices 5, 30..35; 4 x 4 at 60 m: 3, 12..15).
-KEEP = {'tile_T33UUB_600.npz': (None, None),
-        'tile_T49JGM_600.npz': ((0, 5, 7, 14, 21, 28, 29, 30, 31, 32, 33, 34, 35), (0, 3, 5, 10, 12, 13, 15))}
 
 
 @pytest.mark.parametrize('name', TILES)
 def test_dsen2_20_on_the_whole_bundled_tile(golden_dir, model_dir, name):
-    """DSen2_20(im10, im20) as testing/demoDSen2.py:42-43 calls it."""
+    """DSen2_20(im10, im20) as testing/demoDSen2.py:42-43 calls it: all 36 patches against the float64 oracle."""
     from dsen2_amd.supres import DSen2_20
     _, d = bands(golden_dir, name)
     out = quiet(DSen2_20, d[0], d[1], deep=False)
     assert out.shape == (600, 600, 6) and out.dtype == np.float32 and np.isfinite(out).all()
     p = po.get_test_patches(d[0], d[1], patchSize=128, border=8, f32_coords=True)
-    ref = oracle_image(p, model_dir['s2_032_lr_1e-04'], 6, 128, 8, d[0].shape, KEEP[name][0])
-    seen = np.isfinite(ref)
-    assert seen.mean() > (0.99 if KEEP[name][0] is None else 0.3)
-    err = float(np.sqrt(np.mean((out[seen] - ref[seen]) ** 2))) / 2000
-    print('%s DSen2_20: normalised rmse %.3e over %.0f %% of the tile' % (name, err, 100 * seen.mean()))
+    ref = oracle_image(p, model_dir['s2_032_lr_1e-04'], 6, 128, 8, d[0].shape)
+    err = do.rmse(out, ref) / 2000
+    print('%s DSen2_20: normalised rmse %.3e' % (name, err))
     assert err < RMSE_GATE_NORMALISED
 
 
 @pytest.mark.parametrize('name', TILES)
 def test_dsen2_60_on_the_whole_bundled_tile(golden_dir, model_dir, name):
-    """DSen2_60(im10, im20, im60) as testing/demoDSen2.py:67-68 calls it."""
+    """DSen2_60(im10, im20, im60) as testing/demoDSen2.py:67-68 calls it: all 16 patches against the float64 oracle."""
     from dsen2_amd.supres import DSen2_60
     _, d = bands(golden_dir, name)
     out = quiet(DSen2_60, d[0], d[1], d[2], deep=False)
     assert out.shape == (600, 600, 2) and out.dtype == np.float32 and np.isfinite(out).all()
     p = po.get_test_patches60(d[0], d[1], d[2], patchSize=192, border=12, f32_coords=True)
-    ref = oracle_image(p, model_dir['s2_030_lr_1e-05'], 2, 192, 12, d[0].shape, KEEP[name][1])
-    seen = np.isfinite(ref)
-    assert seen.mean() > (0.99 if KEEP[name][1] is None else 0.3)
-    err = float(np.sqrt(np.mean((out[seen] - ref[seen]) ** 2))) / 2000
-    print('%s DSen2_60: normalised rmse %.3e over %.0f %% of the tile' % (name, err, 100 * seen.mean()))
+    ref = oracle_image(p, model_dir['s2_030_lr_1e-05'], 2, 192, 12, d[0].shape)
+    err = do.rmse(out, ref) / 2000
+    print('%s DSen2_60: normalised rmse %.3e' % (name, err))
     assert err < RMSE_GATE_NORMALISED

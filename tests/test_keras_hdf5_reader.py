@@ -13,7 +13,8 @@ h5py = pytest.importorskip('h5py')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def write_keras_like(path, cin, cout, d, f, flat, first_index=1, shuffle_names=False, bias_first=False):
+def write_keras_like(path, cin, cout, d, f, flat, first_index=1, shuffle_names=False, bias_first=False, scope='',
+                     conv_name=None):
     from dsen2_amd import weights as W
     shapes = W.layer_shapes(cin, cout, d, f)
     names, off = [], 0
@@ -24,10 +25,10 @@ def write_keras_like(path, cin, cout, d, f, flat, first_index=1, shuffle_names=F
             wn = []
             if weights is not None:
                 k, b = weights
-                sub = g.create_group(name)
+                sub = g.create_group(name + scope)      # scope='_1': a name scope TensorFlow made unique
                 sub.create_dataset('kernel:0', data=k)
                 sub.create_dataset('bias:0', data=b)
-                wn = [('%s/kernel:0' % name).encode(), ('%s/bias:0' % name).encode()]
+                wn = [('%s%s/kernel:0' % (name, scope)).encode(), ('%s%s/bias:0' % (name, scope)).encode()]
                 if bias_first:
                     wn.reverse()
             g.attrs['weight_names'] = wn
@@ -38,7 +39,7 @@ def write_keras_like(path, cin, cout, d, f, flat, first_index=1, shuffle_names=F
             k = flat[off:off + 9 * a * o].reshape(3, 3, a, o); off += 9 * a * o
             b = flat[off:off + o]; off += o
             ci += 1
-            add('conv2d_%d' % ci, (k, b))
+            add(conv_name(li) if conv_name else 'conv2d_%d' % ci, (k, b))
             if 0 < li < len(shapes) - 1:
                 add('activation_%d' % ci if li % 2 == 1 else 'lambda_%d' % ci)
                 if li % 2 == 0:
@@ -71,6 +72,27 @@ def test_reader_does_not_trust_attribute_or_weight_order(tmp_path):
         p = str(tmp_path / ('s2_030_%s.hdf5' % '_'.join(sorted(kw))))
         write_keras_like(p, 12, 2, 6, 128, flat, **kw)
         assert np.array_equal(W.load_flat(p, 12, 2, 6, 128), flat), kw
+
+
+def test_reader_accepts_tf_keras_names_unique_scopes_and_unnumbered_layers(tmp_path):
+    """(a) tf.keras numbers 'conv2d', 'conv2d_1', ... (the first layer has no suffix); (b) a weight path whose
+    scope TensorFlow made unique ('conv2d_1_1/kernel:0' under layer 'conv2d_1') is legitimate; (c) layer names without
+    a usable numbering fall back to the file's layer_names order — validated by the shape chain, not by names."""
+    from dsen2_amd import weights as W
+    flat = W.random_he_uniform(10, 6, 2, 128, seed=6, bias_scale=0.1)
+    cases = dict(tf=dict(conv_name=lambda li: 'conv2d' if li == 0 else 'conv2d_%d' % li),
+                 scope=dict(scope='_1'),
+                 unnumbered=dict(conv_name=lambda li: 'layer_' + 'abcdefgh'[li]),
+                 repeated=dict(conv_name=lambda li: 'block%d_conv_1' % li))
+    for tag, kw in cases.items():
+        p = str(tmp_path / ('%s.hdf5' % tag))
+        write_keras_like(p, 10, 6, 2, 128, flat, **kw)
+        assert np.array_equal(W.load_flat(p, 10, 6, 2, 128), flat), tag
+    # unnumbered AND shuffled: no order can be trusted, and the shape chain says so
+    p = str(tmp_path / 'hopeless.hdf5')
+    write_keras_like(p, 10, 6, 2, 128, flat, conv_name=lambda li: 'layer_' + 'abcdefgh'[li], shuffle_names=True)
+    with pytest.raises(ValueError):
+        W.load_flat(p, 10, 6, 2, 128)
 
 
 def test_reader_rejects_a_layer_that_is_not_a_conv(tmp_path):

@@ -4,13 +4,11 @@ end to end through the drop-in surface (host ndarray in, host ndarray out), on o
 GPUs of a node (one process per GPU; the inner crops of the predictions are gathered to rank 0 over RCCL, which
 recomposes and returns the image — every other rank gets None: dsen2_amd/dist.py).
 
-    python tools/bench_full_tile.py [--size 10980] [--skip60]
+    python tools/bench_full_tile.py [--size 10980] [--skip60] [--precision fp32|bf16] [--deep]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_full_tile.py
     (--backend gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks)
 Rank 0 prints one JSON line with wall times.  Random-init weights; the data is synthetic.
 """
-import os
-os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # RCCL between processes: dmabuf IPC
 import argparse
 import contextlib
 import io
@@ -31,21 +29,16 @@ ap.add_argument('--size', type=int, default=10980)
 ap.add_argument('--skip60', action='store_true')
 ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'])
 ap.add_argument('--check', action='store_true', help='multi-rank: also verify the result against a single-rank run')
+ap.add_argument('--precision', default=None, choices=['fp32', 'bf16'], help="supres.PRECISION (default: DSEN2_PRECISION or fp32)")
+ap.add_argument('--deep', action='store_true', help='VDSen2 (d=32, F=256) instead of DSen2')
 ap.add_argument('--port', type=int, default=0, help=argparse.SUPPRESS)
 args = ap.parse_args()
 
 import torch.distributed as td      # noqa: E402
-world = int(os.environ.get('WORLD_SIZE', '1'))
-rank = int(os.environ.get('RANK', '0'))
-local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-dev_index = local_rank if args.backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
-torch.cuda.set_device(dev_index)
-if world > 1:
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    if args.backend == 'nccl':
-        td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev_index))
-    else:
-        td.init_process_group('gloo', rank=rank, world_size=world)
+from dsen2_amd import dist          # noqa: E402
+rank, world, _ = dist.init_from_env(args.backend)       # LOCAL_RANK's GPU, dmabuf-IPC environment, process group
+if args.precision:
+    supres.PRECISION = args.precision
 
 n = args.size - args.size % 6
 rng = np.random.default_rng(0)
@@ -53,10 +46,14 @@ d10 = rng.integers(35, 13110, size=(n, n, 4), dtype=np.uint16)
 d20 = rng.integers(35, 13110, size=(n // 2, n // 2, 6), dtype=np.uint16)
 d60 = rng.integers(35, 13110, size=(n // 6, n // 6, 2), dtype=np.uint16)
 tmp = tempfile.mkdtemp()
-np.save(os.path.join(tmp, 's2_032_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 6, 128, seed=11))
-np.save(os.path.join(tmp, 's2_030_lr_1e-05.npy'), weights.random_he_uniform(12, 2, 6, 128, seed=12))
+if args.deep:                       # testing/supres.py:55-57: VDSen2 reads s2_033 / s2_034
+    np.save(os.path.join(tmp, 's2_033_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 32, 256, seed=13))
+    np.save(os.path.join(tmp, 's2_034_lr_1e-04.npy'), weights.random_he_uniform(12, 2, 32, 256, seed=14))
+else:
+    np.save(os.path.join(tmp, 's2_032_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 6, 128, seed=11))
+    np.save(os.path.join(tmp, 's2_030_lr_1e-05.npy'), weights.random_he_uniform(12, 2, 6, 128, seed=12))
 supres.MDL_PATH = os.path.join(tmp, '')
-out = {'tile': [n, n], 'data': 'synthetic', 'n_gpus': world, 'patches20': int(np.ceil(n / 112.0) ** 2), 'patches60': int(np.ceil(n / 168.0) ** 2)}
+out = {'tile': [n, n], 'data': 'synthetic', 'n_gpus': world, 'precision': supres.PRECISION, 'deep': bool(args.deep), 'patches20': int(np.ceil(n / 112.0) ** 2), 'patches60': int(np.ceil(n / 168.0) ** 2)}
 
 
 def timed(fn, *a):
@@ -69,8 +66,8 @@ def timed(fn, *a):
 
 
 with contextlib.redirect_stdout(io.StringIO()):
-    supres.DSen2_20(d10[:240, :240], d20[:120, :120])       # warm-up: library load, model build, weight upload
-y20, t20 = timed(supres.DSen2_20, d10, d20)
+    supres.DSen2_20(d10[:240, :240], d20[:120, :120], args.deep)       # warm-up: library load, model build, weight upload
+y20, t20 = timed(supres.DSen2_20, d10, d20, args.deep)
 if world > 1:                       # whole-job wall time: the slowest rank's
     tt = torch.tensor([t20], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
     td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -84,8 +81,8 @@ else:
     assert y20 is None              # only rank 0 receives, recomposes and downloads
 if not args.skip60:
     with contextlib.redirect_stdout(io.StringIO()):
-        supres.DSen2_60(d10[:384, :384], d20[:192, :192], d60[:64, :64])
-    y60, t60 = timed(supres.DSen2_60, d10, d20, d60)
+        supres.DSen2_60(d10[:384, :384], d20[:192, :192], d60[:64, :64], args.deep)
+    y60, t60 = timed(supres.DSen2_60, d10, d20, d60, args.deep)
     if world > 1:
         tt = torch.tensor([t60], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
         td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -99,10 +96,8 @@ if world > 1 and args.check:
     td.destroy_process_group()            # dist.rank_world() now reports (0, 1): every rank computes everything
     if rank == 0:
         with contextlib.redirect_stdout(io.StringIO()):
-            ref = supres.DSen2_20(d10, d20)
+            ref = supres.DSen2_20(d10, d20, args.deep)
         out['matches_single_rank'] = bool(np.array_equal(ref, y20))
 if rank == 0:
     print(json.dumps(out))
-if world > 1 and td.is_initialized():
-    td.barrier()
-    td.destroy_process_group()
+dist.finalize()
