@@ -8,6 +8,7 @@ H2D/D2H copies and the stream.
 """
 import ctypes
 import sys
+import threading
 
 import numpy as np
 import torch
@@ -47,7 +48,11 @@ class S2Model(object):
             self.precision = precision
             _lib.call('dsen2_model_create', ctypes.byref(self._handle), self.bands[0], self.bands[1], c60,
                       self.num_layers, self.feature_size, 1 if precision == 'bf16' else 0)
-        self._workspace = None
+        # One workspace per STREAM the model is used from (keyed by the stream's handle): SURVEY §8(b) — "calls on a
+        # handle are serialised by the given stream" — so forwards enqueued on different streams, from one thread or
+        # several, must not share the activation buffers the kernels of both would be writing.
+        self._workspaces = {}
+        self._ws_lock = threading.Lock()
         self.max_workspace_bytes = 6 << 30   # predict() sizes its internal batches to stay below this
 
     # -- keras.Model surface -------------------------------------------------------------------
@@ -69,10 +74,22 @@ class S2Model(object):
         return out.value
 
     def _get_workspace(self, nbytes):
-        if self._workspace is None or self._workspace.numel() < nbytes:
-            self._workspace = None
-            self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._workspace
+        """The current stream's workspace, grown on demand.  Allocated under that stream, so torch's caching allocator
+        hands a replaced (smaller) buffer back only to work ordered after the kernels still reading it."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        with self._ws_lock:
+            ws = self._workspaces.get(key)
+            if ws is None or ws.numel() < nbytes:
+                self._workspaces.pop(key, None)
+                ws = None
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                self._workspaces[key] = ws
+            return ws
+
+    def release_workspaces(self):
+        """Drop every stream's activation buffers (they are re-created on the next forward)."""
+        with self._ws_lock:
+            self._workspaces.clear()
 
     def forward_device(self, xs, out=None):
         """One batch entirely on the device: xs = list of contiguous float32 CUDA tensors [n,c,h,w]."""
@@ -130,7 +147,8 @@ class S2Model(object):
         ``batch_size`` only bounds device memory (results do not depend on it); default: as many
         patches as fit ``max_workspace_bytes``.  Host<->device copies go through page-locked buffers on their own
         streams; with more than one batch, batch i+1 is staged and batch i-1 downloaded while batch i computes.
-        A model's workspace is one buffer: use a model from one stream / thread at a time.
+        Activation buffers are per stream: a model may be used from several streams / threads at once (the weights
+        are read-only after load_weights).
         """
         xs = [np.ascontiguousarray(a, dtype=np.float32) for a in x]
         if len(xs) != len(self.bands):

@@ -339,22 +339,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body32_kernel(const ConvPa
 template <int CIN, int COUT, int EPI, int ABL = 0, int PRE = 0, bool STG = false, bool DEFER = false>
 static hipError_t launch_body32_one(const ConvParams& p, hipStream_t stream) {
   auto kern = conv3x3_body32_kernel<CIN, COUT, EPI, ABL, PRE, STG, DEFER>;
-  static bool attr_set[64] = {};
-  static int cus[64] = {};
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
+  static KernelOnce once;
+  int cus = 0;
+  hipError_t e = once.prepare(reinterpret_cast<const void*>(kern), LDS_BYTES, &cus);
   if (e != hipSuccess) return e;
-  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  if (!attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return e;
-    attr_set[dev] = true;
-  }
   const long long items = (long long)p.n * p.tiles_x * p.tiles_y * (COUT / NT);
   if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;
-  const int grid = (int)(items < cus[dev] ? items : cus[dev]);
+  const int grid = (int)(items < cus ? items : cus);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, stream, p, (int)items);
   return hipGetLastError();
 }

@@ -288,16 +288,9 @@ template <int CIN, int KC, int COUT, int NT, int EPI, int NWAVES = 8, int WAVES_
 static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
   using C = ConvCfg<CIN, KC, NT, NWAVES>;
   auto kern = conv3x3_mfma_kernel<CIN, KC, COUT, NT, EPI, NWAVES, WAVES_PER_SIMD, CREAL>;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
+  static KernelOnce once;
+  hipError_t e = once.prepare(reinterpret_cast<const void*>(kern), C::LDS_BYTES, nullptr);
   if (e != hipSuccess) return e;
-  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)C::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set[dev] = true;
-  }
   const long long tiles = (long long)p.n * p.tiles_x * p.tiles_y;
   if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)tiles, COUT / NT, 1);

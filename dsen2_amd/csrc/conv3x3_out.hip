@@ -162,17 +162,9 @@ __global__ __launch_bounds__(outv::THREADS, 2) void conv3x3_out_valu_kernel(cons
 template <int CIN, int NSLOT>
 static hipError_t launch_out_valu_one(const ConvParams& p, hipStream_t stream) {
   auto kern = conv3x3_out_valu_kernel<CIN, NSLOT>;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
+  static KernelOnce once;
+  hipError_t e = once.prepare(reinterpret_cast<const void*>(kern), outv::LDS_BYTES, nullptr);
   if (e != hipSuccess) return e;
-  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  if (!attr_set[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)outv::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set[dev] = true;
-  }
   const long long tiles = (long long)p.n * p.tiles_x * p.tiles_y;
   if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(outv::THREADS), outv::LDS_BYTES, stream, p);

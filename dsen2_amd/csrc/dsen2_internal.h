@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 namespace dsen2 {
 
 // ---- data layout ------------------------------------------------------------------------------
@@ -54,6 +56,34 @@ struct Tuning {
                            // 0 = padded 32-wide MFMA block (conv3x3_mfma.hip, the reference structure)
   int ablate = 0;          // timing-only ablation mask of the persistent body kernels (DSEN2_DIAG builds; wrong outputs)
   int grid_cap = 0;        // DSEN2_DIAG builds: launch at most this many workgroups of the bf16 body kernel (0 = one per CU)
+};
+
+// Per-kernel launch preparation: the dynamic-LDS attribute is a property of (kernel, device) and is set once per pair,
+// under a mutex — host threads driving different devices (or one device from several streams) may reach a launcher
+// at the same time.  One function-local static instance per kernel instantiation (its construction is thread-safe).
+struct KernelOnce {
+  std::mutex mu;
+  bool done[64] = {};
+  int cus[64] = {};
+  // current device -> *dev_cus (its CU count); sets MaxDynamicSharedMemorySize of `kern` there on first use
+  hipError_t prepare(const void* kern, size_t lds_bytes, int* dev_cus) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done[dev]) {
+      if (lds_bytes > 0) {
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+      }
+      e = hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev);
+      if (e != hipSuccess) return e;
+      done[dev] = true;
+    }
+    if (dev_cus) *dev_cus = cus[dev];
+    return hipSuccess;
+  }
 };
 
 // Supported (CIN_PAD, COUT_PAD, epilogue) combinations; returns hipErrorInvalidValue otherwise.

@@ -192,11 +192,17 @@ def _host_output(shape):
 def DSen2_20(d10, d20, deep=False):
     """20 m -> 10 m.  d10 [x, y, 4] (B2 B3 B4 B8), d20 [x/2, y/2, 6] (B5 B6 B7 B8A B11 B12), any real dtype, HWC.
     deep=True selects VDSen2 (d=32, F=256).  Returns [x, y, 6] float32.  Geometry of testing/supres.py:21-22:
-    patches of 128 with an 8-pixel border."""
+    patches of 128 with an 8-pixel border.
+
+    With torch.distributed initialised (one process per GPU; every rank must make the same call with the same
+    arrays — the call contains a collective) the patches are sharded over the ranks and ONLY RANK 0 returns the
+    image; every other rank returns None.  The reference script's `if sr20 is None: exit` branch
+    (testing/s2_tiles_supres.py:346-348) is what a non-root rank then takes."""
     return _run([d10, d20], [2, 1], patch=128, border=8, deep=deep, run_60=False)
 
 
 def DSen2_60(d10, d20, d60, deep=False):
     """60 m -> 10 m.  As DSen2_20 plus d60 [x/6, y/6, 2] (B1 B9; B10 is not super-resolved).  Returns [x, y, 2]
-    float32.  Geometry of testing/supres.py:40-41: patches of 192 with a 12-pixel border."""
+    float32.  Geometry of testing/supres.py:40-41: patches of 192 with a 12-pixel border.  Under torch.distributed: the
+    image on rank 0, None on every other rank (see DSen2_20)."""
     return _run([d10, d20, d60], [6, 3, 1], patch=192, border=12, deep=deep, run_60=True)

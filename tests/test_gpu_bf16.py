@@ -53,6 +53,23 @@ def test_split_join_round_trips_every_kind_of_value():
     assert rel.max() <= 2.0 ** -8
 
 
+@pytest.mark.parametrize('c,n,h,w', [(512, 2, 5, 13), (8, 3, 7, 9), (504, 1, 1, 33)])
+def test_split_join_at_the_documented_channel_limits(c, n, h, w):
+    """include/dsen2_hip.h: c % 8 == 0, c <= 512.  c = 512 needs 66,048 B of dynamic LDS — above the 64 KiB a kernel
+    gets without the MaxDynamicSharedMemorySize attribute; c = 520 is refused, not launched."""
+    from dsen2_amd import _lib
+    from dsen2_amd.DSen2Net import from_blocked, join_f32, split_f32
+    u = np.random.default_rng(c).integers(0, 2 ** 32, size=n * h * w * c, dtype=np.uint64).astype(np.uint32)
+    x = torch.from_numpy(u.view(np.float32).reshape(n, h, w, c)).cuda()
+    hi, lo = split_f32(x)
+    eh, el = np_split(u)
+    assert np.array_equal(from_blocked(hi).cpu().numpy().view(np.uint16).ravel(), eh)
+    assert np.array_equal(from_blocked(lo).cpu().numpy().view(np.uint16).ravel(), el)
+    assert np.array_equal(join_f32(hi, lo).cpu().numpy().view(np.uint32).ravel(), u)
+    with pytest.raises(RuntimeError):
+        split_f32(torch.zeros((1, 2, 2, 520), device='cuda'))
+
+
 @pytest.mark.parametrize('feat,n,h,w', [(256, 2, 32, 32), (256, 1, 21, 37), (128, 2, 32, 32), (128, 1, 16, 48),
                                         (256, 1, 16, 33), (128, 3, 5, 70), (256, 1, 1, 1)])
 def test_bf16_conv_relu_exact_products(feat, n, h, w):

@@ -152,3 +152,45 @@ def test_first_layer_without_padding_mfmas_gives_the_same_bits(bands, feat):
     a = conv3x3_nhwc(x16, k16, b0, epilogue=0)
     y_ref = conv3x3_nhwc(a, k1, b1, epilogue=2, aux=dev[-1])
     assert torch.equal(y, y_ref)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_one_model_on_two_streams_and_two_threads(precision):
+    """calls on a handle are serialised by the stream they are given, so one model used from two streams
+    (forwards enqueued alternately, nothing synchronised in between: their kernels interleave layer by layer) and from
+    two host threads must give each caller the result of its own inputs — every stream has its own activation
+    workspace (S2Model._get_workspace); with a shared one the second stream overwrites the first one's layers."""
+    import threading
+    from dsen2_amd.DSen2Net import s2model
+    flat = do.he_uniform_weights(10, 6, 6, 128, seed=5, bias_scale=0.02)
+    m = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128, precision=precision)
+    m.set_weights_flat(flat)
+    dev = m.device
+    ins = [[torch.from_numpy(a).to(dev) for a in do.synthetic_inputs(64, 32, 32, (4, 6), seed=s)] for s in (11, 12)]
+    want = [m.forward_device(x).clone() for x in ins]          # one at a time, default stream
+    torch.cuda.synchronize()
+    assert not torch.equal(want[0], want[1])
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    got = [None, None]
+    for rep in range(3):
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                got[k] = m.forward_device(ins[k])
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert len(m._workspaces) == 3                               # default stream + the two side streams
+
+    def worker(k):
+        with torch.cuda.device(dev), torch.cuda.stream(streams[k]):
+            for _ in range(3):
+                got[k] = m.forward_device(ins[k])
+            streams[k].synchronize()
+    got = [None, None]
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    m.release_workspaces()
+    assert torch.equal(m.forward_device(ins[0]), want[0])
