@@ -9,7 +9,9 @@ the two translation units to ISA with exactly the product's flags and fails (Asm
     statements preserve it themselves);
   * every `buffer_load_dwordx4 ... lds` is one of those statements;
   * no kernel spills (a scratch access is a vector-memory operation: hipcc waits for a reload with vmcnt(0), which
-    drains the DMA queue, and it is not in the hand counts);
+    drains the DMA queue, and it is not in the hand counts) — the chain kernel (one launch over all body layers, three
+    epilogue forms in one kernel) may spill a few values ACROSS its item loops, i.e. at a layer boundary where the
+    workgroup drains everything anyway, but never between the first and the last MFMA of a nine-step item body;
   * every kernel ends with `s_waitcnt vmcnt(0)` before `s_endpgm` (no DMA may still be writing LDS that already
     belongs to the next workgroup);
   * the bf16 kernel's epilogues contain exactly the number of vector-memory operations its first-chunk waits count
@@ -84,7 +86,7 @@ def check_listing(text, src):
         need(i in allowed, 'M0 touched outside a DMA statement', code[max(0, i - 2):i + 3])
     saves = sum(1 for ln in code if re.match(r's_mov_b32 (s\d+|vcc_lo|vcc_hi), m0$', ln))
     need(saves > 0, 'the DMA statements no longer save M0')
-    need(not any('scratch_' in ln for ln in code), 'a DMA kernel spills registers')
+    STEP_MFMAS = 9 * 32                 # bf16 kernel: MFMAs of one copy of the nine-step body (4 x 8 per step)
     need(not any(ln.startswith(('s_swappc', 's_call')) for ln in code), 'a DMA kernel calls a function (an epilogue was not inlined)')
     kernels = _kernels(text)
     need(kernels, 'no kernel found')
@@ -93,6 +95,15 @@ def check_listing(text, src):
         if not any(ln.startswith('buffer_load_dwordx4') and ln.endswith('lds') for ln in body):
             continue                       # a kernel without LDS-DMA (the split / join helpers)
         n_dma_kernels += 1
+        chain = '_chain_kernel' in name
+        if not chain:
+            need(not any('scratch_' in ln for ln in body), 'kernel %s spills registers' % name)
+        else:
+            mf = [i for i, ln in enumerate(body) if ln.startswith('v_mfma')]
+            need(mf and len(mf) % STEP_MFMAS == 0, 'chain kernel %s: %d MFMAs is not a whole number of item bodies' % (name, len(mf)))
+            for g in range(0, len(mf), STEP_MFMAS):
+                inner = body[mf[g]:mf[g + STEP_MFMAS - 1]]
+                need(not any('scratch_' in ln for ln in inner), 'chain kernel %s spills inside an item body' % name)
         back = [ln for ln in body[-40:] if ln.startswith('s_waitcnt') and 'vmcnt' in ln]
         need(back and back[-1].replace(' ', '') in ('s_waitcntvmcnt(0)', 's_waitcntvmcnt(0)lgkmcnt(0)'),
              'kernel %s does not drain its DMAs before s_endpgm' % name, back[-3:])
@@ -117,6 +128,18 @@ def check_listing(text, src):
             need((loads, stores) == expect[int(m.group(3))],
                  'epilogue %s has %d loads / %d stores, the waits count %r' % (m.group(3), loads, stores, expect[int(m.group(3))]))
         need(found >= 6, 'expected the 6 product instantiations of the bf16 body kernel, found %d' % found)
+        # the chain kernel holds all three epilogues, each in both copies of the item loop
+        chains = 0
+        for name, body in _kernels(text).items():
+            m = re.search(r'conv3x3_body16w_chain_kernelILi(\d+)ELi(\d+)ELi(\d+)E', name)
+            if not m or int(m.group(3)) != 0:
+                continue
+            chains += 1
+            loads = sum(1 for ln in body if ln.startswith('buffer_load_dwordx4') and not ln.endswith('lds'))
+            stores = sum(1 for ln in body if ln.startswith('buffer_store_dwordx4'))
+            want = (sum(v[0] for v in expect.values()), sum(v[1] for v in expect.values()))
+            need((loads, stores) == want, 'chain kernel has %d loads / %d stores in its epilogues, the waits count %r' % (loads, stores, want))
+        need(chains == 2, 'expected the 2 product instantiations of the chain kernel, found %d' % chains)
 
 
 def check_sources(hipcc, flags, verbose=False):

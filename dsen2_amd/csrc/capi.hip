@@ -67,6 +67,7 @@ struct dsen2_model {
   Tuning tune;          // kernel structures, fixed at creation
   std::vector<Layer> layers;
   size_t n_params;
+  size_t chain_stride;  // precision 1: bytes between the packed weights (= between the biases) of consecutive body layers; 0 = not uniform
   size_t dev_param_floats;
   float* dev_params;
   bool loaded;
@@ -105,6 +106,10 @@ int dsen2_diag_set(int key, int value) {
   }
   if (key == 3) {   // at most `value` workgroups for the bf16 body kernel (0 = one per CU): per-CU vs chip-wide limits
     g_diag_tuning.grid_cap = value;
+    return DSEN2_OK;
+  }
+  if (key == 4) {   // 0 = always launch the bf16 body convolutions layer by layer (A/B against the chain kernel)
+    g_diag_tuning.chain = value;
     return DSEN2_OK;
   }
   return fail(DSEN2_ERR_INVALID, "unknown diagnostic key %d", key);
@@ -179,6 +184,16 @@ int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_lay
   }
   m->n_params = flat;
   m->dev_param_floats = dev;
+  // the chain kernel (one launch over all body layers) addresses layer l's weights and bias at l * chain_stride
+  m->chain_stride = 0;
+  if (precision == 1 && num_layers > 0) {
+    const size_t stride = m->layers[2].w_off - m->layers[1].w_off;
+    bool uniform = true;
+    for (int l = 1; l <= 2 * num_layers; ++l)
+      uniform = uniform && m->layers[l].bf16 && m->layers[l].w_off == m->layers[1].w_off + (size_t)(l - 1) * stride &&
+                m->layers[l].b_off == m->layers[1].b_off + (size_t)(l - 1) * stride;
+    if (uniform) m->chain_stride = stride * sizeof(float);
+  }
   *out = m;
   return DSEN2_OK;
 }
@@ -222,7 +237,8 @@ int dsen2_model_workspace_bytes(const dsen2_model* m, int n, int h, int w, size_
 }
 
 static hipError_t launch_bf16_body(const ConvParams& p, int feat, int epilogue, const Tuning& t, hipStream_t stream) {
-  return launch_conv3x3_body16w(p, feat, epilogue, t.ablate, stream, t.grid_cap);
+  // (masks from 1024 up belong to the chain kernel)
+  return launch_conv3x3_body16w(p, feat, epilogue, t.ablate & 1023, stream, t.grid_cap);
 }
 
 static int check_shape(const dsen2_model* m, int n, int h, int w) {
@@ -287,7 +303,20 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
     void* lo = t + half;
     void* tbf = t + 2 * half;
     if (ev_body0) HIP_TRY(hipEventRecord(ev_body0, stream));
-    for (int i = 0; i < m->num_layers; ++i) {
+    // One persistent launch over all 2d body convolutions when every CU gets whole patches (batch >= one patch per CU,
+    // e.g. BASELINE configs[4]); hipErrorNotSupported = this batch keeps more CUs busy layer by layer.
+    hipError_t chained = hipErrorNotSupported;
+    if (m->chain_stride != 0 && m->tune.chain && m->tune.grid_cap == 0) {
+      const Layer& L1 = m->layers[li];
+      ConvParams pc = make_params(nullptr, P + L1.w_off, P + L1.b_off, nullptr, nullptr, n, h, w, 0, 0.1f);
+      ChainArgs ca;
+      ca.hi = hi; ca.lo = lo; ca.t = tbf; ca.out_f32 = a;
+      ca.layer_stride = (unsigned)m->chain_stride; ca.n_layers = 2 * m->num_layers; ca.patches_per_wg = 0;
+      chained = launch_conv3x3_body16w_chain(pc, ca, m->feat, stream, m->tune.ablate);
+      if (chained == hipSuccess) li += 2 * (size_t)m->num_layers;
+      else if (chained != hipErrorNotSupported) return fail(DSEN2_ERR_HIP, "chain kernel launch: %s", hipGetErrorString(chained));
+    }
+    for (int i = 0; i < m->num_layers && chained != hipSuccess; ++i) {
       const Layer& LA = m->layers[li++];
       ConvParams pa = make_params(reinterpret_cast<const float*>(hi), P + LA.w_off, P + LA.b_off, nullptr,
                                   reinterpret_cast<float*>(tbf), n, h, w, 0, 0.f);

@@ -103,17 +103,30 @@ constexpr int younger_than_input(bool has_w) { return has_w ? 4 * W_PER_STEP : 0
 // (1 no stores, 2 no residual loads, 4 no weight stream, 8 no input stream, 16 no barriers; 32 = full kernel + time stamps;
 // 128 / 256 = only the issuing / only the compute-only waves skip their stores).  The closed experiments' masks (512 / 1536:
 // epilogue traffic trickled under the next item; 2048: 8-bit lo plane) live in experiments/conv3x3_body16w_closed_masks.hip.txt.
-template <int CINW, int COUT, int EPI, int ABL>
-__global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvParams p, const int n_items) {
+//
+// CHAIN (conv3x3_body16w_chain_kernel): ONE launch runs all 2d residual-block convolutions of a precision-1 network.
+// A workgroup owns whole patches — every item of `patches_per_wg` consecutive images, layer after layer — so a layer's
+// input was written by the same workgroup: no flag, no grid barrier, no cross-XCD visibility question; between two
+// layers the workgroup drains its own stores (vmcnt(0) + barrier: workgroup-scope release / acquire on one CU) and
+// stages the next layer's first input chunk.  The weight stream runs across the layer boundary (the packed weights of
+// consecutive body layers are `layer_stride` bytes apart in one buffer), so the ring is already full when a layer
+// starts.  EPI is then chosen per layer: conv-A (even) kEpiRelu hi -> t, conv-B (odd) kEpiResidual in place on
+// (hi, lo), the last one kEpiResidualF32 -> out_f32.  Same arithmetic per item as the per-layer kernels: same bits.
+
+template <int ABL>
+__host__ __device__ constexpr int epilogue_ops(int epi) {
+  // vector-memory operations of one epilogue (per wave): 16 groups of 8 channels x (stores + residual loads)
+  // (diagnostic mask 128: the ISSUING waves 0-3 skip their epilogue stores, the compute-only waves keep theirs — the
+  // waits exist in the issuers' code only, so the count is theirs; mask 256: the other way round)
+  return ((ABL & (1 | 128)) ? 0 : (epi == kEpiRelu ? 16 : 32)) + (epi != kEpiRelu && !(ABL & 2) ? 32 : 0);
+}
+
+template <int CINW, int COUT, int EPI0, int ABL, bool CHAIN>
+__device__ __forceinline__ void body16w(const ConvParams p, const int n_items, const ChainArgs chain) {
   constexpr int NCC = CINW / 16;              // 32-channel chunks
   constexpr int NCHUNK = NCC * 9;
   constexpr int NS = COUT / 128;
   constexpr bool kW = !(ABL & 4), kIn = !(ABL & 8);
-  constexpr bool kRes = EPI != kEpiRelu;
-  // vector-memory operations of one epilogue (per wave): 16 groups of 8 channels x (stores + residual loads)
-  // (diagnostic mask 128: the ISSUING waves 0-3 skip their epilogue stores, the compute-only waves keep theirs — the
-  // waits exist in the issuers' code only, so E_OPS is theirs; mask 256: the other way round)
-  constexpr int E_OPS = ((ABL & (1 | 128)) ? 0 : (EPI == kEpiRelu ? 16 : 32)) + (kRes && !(ABL & 2) ? 32 : 0);
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const in_s = reinterpret_cast<char*>(smem);                       // [2][4][QS][16 B]
@@ -126,41 +139,73 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   const int wn = wave & 1;                 // 64-channel half of the slab
   const int wp = wave >> 1;                // pixel quarter of the tile: 8 rows x 16 columns
   const int wrow = 8 * (wp >> 1), wcol = 16 * (wp & 1);
-  const int l15 = lane & 15;
-  const int q4 = lane >> 4;
+  int l15 = lane & 15;
+  int q4 = lane >> 4;
 
   // persistent schedule: logical ids remapped so that each XCD (blockIdx % 8) walks a contiguous run of items
   const int G = gridDim.x;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  if (lid >= n_items) return;
-  const int my_items = (n_items - lid + G - 1) / G;
-  const int tiles_per_img = p.tiles_x * p.tiles_y;
-  const size_t img_pix = (size_t)p.h * p.w;
+  // Layer-invariant values the lambdas below use.  In a CHAIN they are passed through an empty asm statement at the
+  // start of every layer (begin_layer): otherwise hipcc hoists what each of the six copies of the item loop derives
+  // from them out of the layer loop and keeps all of it alive across all copies — more scalars than there are SGPRs.
+  int W_ = p.w, H_ = p.h, TX_ = p.tiles_x, TPI_ = p.tiles_x * p.tiles_y;
+  float RS_ = p.res_scale;
+  // items this workgroup walks (per layer): item0, item0 + istep, ... (my_items of them)
+  int item0, my_items;
+  const int istep = CHAIN ? 1 : G;
+  if constexpr (CHAIN) {
+    const int first_img = lid * chain.patches_per_wg;
+    const int imgs = p.n - first_img < chain.patches_per_wg ? p.n - first_img : chain.patches_per_wg;
+    if (imgs <= 0) return;
+    item0 = first_img * TPI_ * NS;
+    my_items = imgs * TPI_ * NS;
+  } else {
+    if (lid >= n_items) return;
+    item0 = lid;
+    my_items = (n_items - lid + G - 1) / G;
+  }
+  size_t IMGPIX_ = (size_t)p.h * p.w;
 
   struct Tile { int img, ty0, tx0, slab; };
   auto tile_of = [&](int item) -> Tile {
     const int tile = item / NS;
-    const int img = tile / tiles_per_img;
-    const int trem = tile - img * tiles_per_img;
-    const int tyi = trem / p.tiles_x;
-    return Tile{img, tyi * TH, (trem - tyi * p.tiles_x) * TW, item - tile * NS};
+    const int img = tile / TPI_;
+    const int trem = tile - img * TPI_;
+    const int tyi = trem / TX_;
+    return Tile{img, tyi * TH, (trem - tyi * TX_) * TW, item - tile * NS};
   };
+
+  // The tensors of a convolution.  Per-layer kernel: the launch's parameters.  CHAIN: a function of the layer's
+  // epilogue only (conv-A hi -> t; conv-B t -> (hi, lo) in place, or -> out_f32 for the last one), i.e. kernel arguments
+  // inside each instantiation of the item loop — nothing per layer has to live in registers across it.
+  auto in_of = [&](auto epi_c) -> const char* {
+    if constexpr (CHAIN) return reinterpret_cast<const char*>(decltype(epi_c)::value == kEpiRelu ? chain.hi : chain.t);
+    else return reinterpret_cast<const char*>(p.in);
+  };
+  auto out_of = [&](auto epi_c) -> char* {
+    constexpr int e = decltype(epi_c)::value;
+    if constexpr (CHAIN) return reinterpret_cast<char*>(e == kEpiRelu ? chain.t : e == kEpiResidual ? chain.hi : (void*)chain.out_f32);
+    else return reinterpret_cast<char*>(p.out);
+  };
+  auto hi_of = [&]() -> char* { return reinterpret_cast<char*>(CHAIN ? chain.hi : (void*)const_cast<float*>(p.aux)); };
+  auto lo_of = [&]() -> char* { return reinterpret_cast<char*>(CHAIN ? chain.lo : p.out2); };
 
   // ---- the two DMA streams ----
   const unsigned lds_in = lds_address(in_s), lds_w = lds_address(w_s);
   const int dq = wave & 3;                         // issuing wave q moves channel group q of every halo pixel
-  __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t w_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (unsigned)(NS * NCHUNK * WCH_BYTES), 0x00020000);
-  const unsigned in_plane_bytes = (unsigned)(img_pix * 16);   // one 8-channel block of one image
+  __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, 0, 0x00020000);   // set per staged item
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wpk), 0,
+      (unsigned)(NS * NCHUNK * WCH_BYTES) + (CHAIN ? (unsigned)(chain.n_layers - 1) * chain.layer_stride : 0u), 0x00020000);
+  unsigned in_plane_bytes = (unsigned)(IMGPIX_ * 16);   // one 8-channel block of one image
   int st_y0 = 0, st_x0 = 0;                        // origin of the tile being staged
-  auto set_stage_item = [&](int item) {
+  auto set_stage_item = [&](auto epi_c, int item) __attribute__((always_inline)) {
     const Tile t = tile_of(item);
     in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(const_cast<float*>(p.in)) + (size_t)t.img * img_pix * CINW * 4, 0,
-        (unsigned)(img_pix * CINW * 4), 0x00020000);
+        const_cast<char*>(in_of(epi_c)) + (size_t)t.img * IMGPIX_ * CINW * 4, 0,
+        (unsigned)(IMGPIX_ * CINW * 4), 0x00020000);
     st_y0 = t.ty0;
     st_x0 = t.tx0;
   };
@@ -174,27 +219,41 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
     const int hp = 64 * b + ln;
     const int hy = (hp * 1928) >> 16, hx = hp - hy * HW;      // hp / 34 for hp < 640
     const int gy = st_y0 - 1 + hy, gx = st_x0 - 1 + hx;
-    const bool inb = hp < HALO && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
+    const bool inb = hp < HALO && (unsigned)gy < (unsigned)H_ && (unsigned)gx < (unsigned)W_;
     // blocked layout: 8-channel block (4*cc + dq) is a plane of 16-byte pixels, so the 64 lanes of a round read
     // runs of consecutive addresses (one run per halo row).  Out of range (any offset >= 2^31) reads zeros = the
     // convolution's padding; no branch
-    const unsigned voff = ((unsigned)(__umul24(gy, p.w) + gx) * 16u + in_plane_bytes * (unsigned)dq) | (inb ? 0u : 0x80000000u);
+    const unsigned voff = ((unsigned)(__umul24(gy, W_) + gx) * 16u + in_plane_bytes * (unsigned)dq) | (inb ? 0u : 0x80000000u);
     const unsigned m0v = lds_in + buf * IN_BYTES + (dq * QS + 64 * b) * 16;
     const unsigned so = (unsigned)(4 * cc) * in_plane_bytes;
     lds_dma(m0v, voff, in_rsrc, so);
   };
   // the next weight chunk of this workgroup's stream (8 wave instructions of 1 KiB, two per issuing wave) into the
-  // next ring slot; the stream runs over item boundaries and, past the last item, wraps to the first one (harmless)
-  int wl_item = lid, wl_chunk = 0, wl_slot = 0;
+  // next ring slot; the stream runs over item boundaries (CHAIN: and over layer boundaries) and, past the last item,
+  // wraps to the first one (harmless)
+  int wl_item = item0, wl_chunk = 0, wl_slot = 0;
+  int wl_left = my_items;                          // CHAIN: items of the stream's layer still to come (this one included)
+  unsigned wl_layer_off = 0;                       // CHAIN: byte offset of the stream's layer inside the weight buffer
   const unsigned w_voff = lane * 16;
   auto issue_w = [&]() __attribute__((always_inline)) {
-    const unsigned so = (unsigned)(((wl_item % NS) * NCHUNK + wl_chunk) * WCH_BYTES + wave * 1024);
+    const unsigned so = (unsigned)(((wl_item % NS) * NCHUNK + wl_chunk) * WCH_BYTES + wave * 1024) + (CHAIN ? wl_layer_off : 0u);
     const unsigned m0v = lds_w + wl_slot * WCH_BYTES + wave * 1024;
     lds_dma(m0v, w_voff, w_rsrc, so);
     lds_dma(m0v + 4096u, w_voff, w_rsrc, so + 4096u);
-    if (++wl_chunk == NCHUNK) {
-      wl_chunk = 0;
-      wl_item = wl_item + G < n_items ? wl_item + G : lid;
+    if constexpr (CHAIN) {
+      // scalar selects only: a branch here would cut the nine-step body into basic blocks (see the step lambda)
+      const bool item_done = wl_chunk == NCHUNK - 1;
+      const bool layer_done = item_done && wl_left == 1;    // on to the next layer's first item (after the last layer: layer 0 again)
+      const unsigned next_off = wl_layer_off + chain.layer_stride;
+      wl_chunk = item_done ? 0 : wl_chunk + 1;
+      wl_item = layer_done ? item0 : item_done ? wl_item + 1 : wl_item;
+      wl_left = layer_done ? my_items : item_done ? wl_left - 1 : wl_left;
+      wl_layer_off = !layer_done ? wl_layer_off : next_off >= (unsigned)chain.n_layers * chain.layer_stride ? 0u : next_off;
+    } else {
+      if (++wl_chunk == NCHUNK) {
+        wl_chunk = 0;
+        wl_item = wl_item + G < n_items ? wl_item + G : lid;
+      }
     }
     wl_slot = wl_slot == RING - 1 ? 0 : wl_slot + 1;
   };
@@ -205,21 +264,43 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   const int x_lane = (q4 * QS + wrow * HW + wcol + l15) * 16;
   const int w_lane = (q4 * 128 + wn * 64 + l15) * 16;
 
-  // ---- prologue: first item's input chunk 0, weight chunks 0 .. LEAD-1 ----
-  set_stage_item(lid);
-  if (wave < 4) {
-    if constexpr (kIn) {
-#pragma unroll
-      for (int r = 0; r < IN_ROUNDS; ++r) issue_in(0, r, 0);
+  // ---- prologue: first item's input chunk 0 (CHAIN: staged per layer, below), weight chunks 0 .. LEAD-1 ----
+  // begin_layer: the layer's bias and its first item's input chunk 0 into LDS, everything in flight retired.  In a
+  // CHAIN the same statement is what makes layer l's outputs (this workgroup's own stores) the input of layer l + 1:
+  // every wave retires its stores (vmcnt(0)), the barrier orders them before the issuing waves' DMA reads.
+  auto begin_layer = [&](auto epi_c, const float* bias) __attribute__((always_inline)) {
+    if constexpr (CHAIN && (ABL & 1024) != 0) return;      // diagnostic mask 1024 (timing only): layers follow each other with no boundary at all
+    if constexpr (CHAIN) {
+      wait_vmcnt<0>();
+      __syncthreads();
+      // (two statements: hipcc treats EVERY output of an asm statement as divergent when one of them is a VGPR)
+      asm volatile("" : "+s"(W_), "+s"(H_), "+s"(TX_), "+s"(TPI_), "+s"(RS_), "+s"(IMGPIX_), "+s"(in_plane_bytes));
+      asm volatile("" : "+v"(l15), "+v"(q4));
     }
+    set_stage_item(epi_c, item0);
+    if (wave < 4) {
+      if constexpr (kIn) {
+#pragma unroll
+        for (int r = 0; r < IN_ROUNDS; ++r) issue_in(0, r, 0);
+      }
+    }
+    if constexpr (CHAIN) {
+      int t = tid;                    // opaque copy: the LDS address is computed here, not kept (spilled) across the layers
+      asm volatile("" : "+v"(t));
+      if (t < COUT) bias_s[t] = bias[t];
+    } else {
+      if (tid < COUT) bias_s[tid] = p.bias[tid];
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+  };
+  if (wave < 4) {
     if constexpr (kW) {
 #pragma unroll
       for (int c = 0; c < LEAD; ++c) issue_w();
     }
   }
-  if (tid < COUT) bias_s[tid] = p.bias[tid];
-  wait_vmcnt<0>();
-  __syncthreads();
+  if constexpr (!CHAIN) begin_layer(std::integral_constant<int, EPI0>{}, p.bias);
 
   // Pixel fragments: XR = PB + 2 halo-row segments (rows wrow + 0..9 of the staged tile, 16 columns from wcol + dx)
   // serve the three taps dy = 0..2 of one dx: MFMA (mb, pb) of tap (dy, dx) multiplies x_row[pb + dy].
@@ -248,7 +329,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
 
   // ---- epilogue of one item: lane = pixel (row wrow + pb, column wcol + l15), group (pr, pb) =
   // 8 consecutive channels slab*128 + wn*64 + 32*pr + 8*q4 held by accumulators 2*pr and 2*pr+1 ----
-  auto epilogue = [&](int item, bool valid) __attribute__((always_inline)) {
+  auto epilogue = [&](auto epi_c, int item, bool valid) __attribute__((always_inline)) {
+    constexpr int EPI = decltype(epi_c)::value;
     const Tile t = tile_of(item);
     const int ch8 = t.slab * 128 + wn * 64 + 8 * q4;
     const int ex = t.tx0 + wcol + l15, ey = t.ty0 + wrow;
@@ -259,22 +341,22 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
     // epilogue before the first item) gets bit 31 set = out of the descriptor's range: every load and store is
     // always ISSUED, which is what the hand-counted waits of the next item's first steps rely on.
     const unsigned blk0 = (unsigned)(ch8 >> 3);                       // + 4*pr
-    const unsigned base_pix = (unsigned)(ey * p.w + ex);
+    const unsigned base_pix = (unsigned)(ey * W_ + ex);
     const unsigned bad_all = valid ? 0u : 0x80000000u;
     auto bad_of = [&](int pb) -> unsigned {
       const int row = ey + pb, col = ex;
-      return bad_all | (row < p.h ? 0u : 0x80000000u) | (col < p.w ? 0u : 0x80000000u);
+      return bad_all | (row < H_ ? 0u : 0x80000000u) | (col < W_ ? 0u : 0x80000000u);
     };
     auto plane_off = [&](int pr, int pb) -> unsigned {                // 16-bit blocked tensors
-      return (((blk0 + 4u * pr) * (unsigned)img_pix + base_pix + (unsigned)(pb * p.w)) * 16u & 0x7fffffffu) | bad_of(pb);
+      return (((blk0 + 4u * pr) * (unsigned)IMGPIX_ + base_pix + (unsigned)(pb * W_)) * 16u & 0x7fffffffu) | bad_of(pb);
     };
     auto nhwc_f32_off = [&](int pr, int pb) -> unsigned {             // fp32 channels-last tensor (kEpiResidualF32)
-      return (((base_pix + (unsigned)(pb * p.w)) * (unsigned)COUT + (unsigned)(ch8 + 32 * pr)) * 4u & 0x7fffffffu) | bad_of(pb);
+      return (((base_pix + (unsigned)(pb * W_)) * (unsigned)COUT + (unsigned)(ch8 + 32 * pr)) * 4u & 0x7fffffffu) | bad_of(pb);
     };
-    const size_t img_elems = img_pix * COUT;
+    const size_t img_elems = IMGPIX_ * COUT;
     if constexpr (EPI == kEpiRelu) {
       const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<char*>(p.out) + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
+          out_of(epi_c) + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
@@ -296,11 +378,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
         }
     } else {
       const auto hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<char*>(const_cast<float*>(p.aux)) + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
+          hi_of() + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
       const auto lo_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<char*>(p.out2) + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
+          lo_of() + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
       const auto f32_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<char*>(p.out) + (EPI == kEpiResidualF32 ? (size_t)t.img * img_elems * 4 : 0), 0,
+          out_of(epi_c) + (EPI == kEpiResidualF32 ? (size_t)t.img * img_elems * 4 : 0), 0,
           EPI == kEpiResidualF32 ? (unsigned)(img_elems * 4) : 0, 0x00020000);
       // pass j = rows wrow + 2j, 2j+1: 4 groups (2 rows x 2 channel pairs).  Residual loads run two passes
       // ahead of the stores in issue order (L0 L1 | C0 L2 S0 | C1 L3 S1 | C2 S2 | C3 S3): only the last pass's
@@ -331,8 +413,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
             unsigned u0, u1;
             join2(rh[j][g][k], rl[j][g][k], u0, u1);
             // x + 0.1 * (conv + b): two roundings like keras (-ffp-contract=off)
-            ov[2 * k] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, u0) + cv[2 * k] * p.res_scale);
-            ov[2 * k + 1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, u1) + cv[2 * k + 1] * p.res_scale);
+            ov[2 * k] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, u0) + cv[2 * k] * RS_);
+            ov[2 * k + 1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, u1) + cv[2 * k + 1] * RS_);
           }
           if constexpr (EPI == kEpiResidual) {
             const unsigned eo = plane_off(pr, pb);
@@ -389,8 +471,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   // Rotated item loop: iteration `it` first writes out item it-1 (the first iteration issues the same loads and
   // stores with out-of-range offsets, so every path into an item's first steps has issued E_OPS operations),
   // then runs item `it`'s NCHUNK steps; one extra iteration writes the last item.
-  auto run = [&](auto issuer_c) __attribute__((always_inline)) {
+  auto run = [&](auto issuer_c, auto epi_c) __attribute__((always_inline)) {
   constexpr bool ISSUER = decltype(issuer_c)::value;
+  constexpr int E_OPS = epilogue_ops<ABL>(decltype(epi_c)::value);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -400,11 +483,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
     stamp_it = it;
     stamp(0);
     stamp(19);
-    epilogue(it > 0 ? lid + (it - 1) * G : lid, it > 0);
+    // (CHAIN: no dummy epilogue before a layer's first item — begin_layer has retired everything older than the
+    // item's own DMAs, so the first-chunk waits, which count E_OPS operations that are then not there, have nothing
+    // older left to protect)
+    if (!CHAIN || it > 0) epilogue(epi_c, it > 0 ? item0 + (it - 1) * istep : item0, it > 0);
     __builtin_amdgcn_sched_barrier(0);
     stamp(1);
     if (it == my_items) break;
-    const int item = lid + it * G;
+    const int item = item0 + it * istep;
     const bool have_next_item = it + 1 < my_items;
     {
       // accumulators start at the bias of their channels: acc[2*pr + e][.][r] <-> channel ch8 + 32*pr + 4*e + r
@@ -438,7 +524,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
       // very last item: its own chunk 0 again, which nobody reads — the operation count stays the same)
       const bool last_cc = cc == NCC - 1;
       const int in_cc = last_cc ? 0 : cc + 1;
-      if (ISSUER && last_cc && have_next_item) set_stage_item(item + G);
+      if (ISSUER && last_cc && have_next_item) set_stage_item(epi_c, item + istep);
       auto step = [&](auto st_c) __attribute__((always_inline)) {
         constexpr int st = decltype(st_c)::value;        // index of the step inside its chunk
         const int nx_slot = mf_slot == RING - 1 ? 0 : mf_slot + 1;
@@ -526,11 +612,37 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
     for (int cc = 0; cc < NCC; ++cc) do_cc(cc);
   }
   };   // run
-  if (wave < 4)
-    run(std::true_type{});
-  else
-    run(std::false_type{});
+  if constexpr (!CHAIN) {
+    if (wave < 4)
+      run(std::true_type{}, std::integral_constant<int, EPI0>{});
+    else
+      run(std::false_type{}, std::integral_constant<int, EPI0>{});
+  } else {
+#pragma unroll 1
+    for (int l = 0; l < chain.n_layers; ++l) {
+      const float* const bias = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.bias) + (size_t)l * chain.layer_stride);
+      auto layer = [&](auto epi_c) __attribute__((always_inline)) {
+        begin_layer(epi_c, bias);
+        if (wave < 4) run(std::true_type{}, epi_c);
+        else run(std::false_type{}, epi_c);
+      };
+      if ((l & 1) == 0) layer(std::integral_constant<int, kEpiRelu>{});
+      else if (l + 1 < chain.n_layers) layer(std::integral_constant<int, kEpiResidual>{});
+      else layer(std::integral_constant<int, kEpiResidualF32>{});
+    }
+  }
   wait_vmcnt<0>();       // no DMA may still be writing this workgroup's LDS when it is released
+}
+
+template <int CINW, int COUT, int EPI, int ABL>
+__global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvParams p, const int n_items) {
+  body16w<CINW, COUT, EPI, ABL, false>(p, n_items, ChainArgs{});
+}
+
+// p.wpk / p.bias: the FIRST body layer's packed weights / bias; p.in, p.out, p.aux, p.out2 are set per layer
+template <int CINW, int COUT, int ABL>
+__global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_chain_kernel(const ConvParams p, const ChainArgs chain) {
+  body16w<CINW, COUT, kEpiRelu, ABL, true>(p, 0, chain);
 }
 
 template <int CINW, int COUT, int EPI, int ABL = 0>
@@ -550,6 +662,49 @@ static hipError_t launch_body16w_one(ConvParams p, hipStream_t stream, int grid_
   if (grid_cap > 0 && grid_cap < grid) grid = grid_cap;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, stream, p, (int)items);
   return hipGetLastError();
+}
+
+template <int CINW, int COUT, int ABL = 0>
+static hipError_t launch_body16w_chain_one(ConvParams p, ChainArgs c, hipStream_t stream) {
+  auto kern = conv3x3_body16w_chain_kernel<CINW, COUT, ABL>;
+  static KernelOnce once;
+  int cus = 0;
+  hipError_t e = once.prepare(reinterpret_cast<const void*>(kern), LDS_BYTES, &cus);
+  if (e != hipSuccess) return e;
+  if ((size_t)p.h * p.w * COUT >= ((size_t)1 << 29)) return hipErrorInvalidValue;
+  p.tiles_x = (p.w + TW - 1) / TW;
+  p.tiles_y = (p.h + TH - 1) / TH;
+  c.patches_per_wg = body16w_chain_patches_per_wg(p.n, p.h, p.w, COUT, cus);
+  if (c.n_layers <= 0) return hipErrorInvalidValue;
+  if (c.patches_per_wg <= 0) return hipErrorNotSupported;       // the per-layer kernels keep more CUs busy for this batch
+  // the weight descriptor spans all layers: 32-bit byte offsets
+  if ((unsigned long long)c.n_layers * c.layer_stride >= 0xffffffffull) return hipErrorInvalidValue;
+  const int grid = (p.n + c.patches_per_wg - 1) / c.patches_per_wg;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, stream, p, c);
+  return hipGetLastError();
+}
+
+// Whole patches per workgroup for the chain kernel, or 0 when a chain would leave CUs idle that the per-layer kernels
+// use: the chain hands out images, the per-layer launch items; chain only if it needs no more item rounds per layer.
+int body16w_chain_patches_per_wg(int n, int h, int w, int feat, int cus) {
+  if (n <= 0 || cus <= 0) return 0;
+  const long long ipp = (long long)((w + TW - 1) / TW) * ((h + TH - 1) / TH) * (feat / 128);    // items per patch
+  const int ppw = (n + cus - 1) / cus;
+  const long long rounds_layerwise = (n * ipp + cus - 1) / cus;
+  return ppw * ipp <= rounds_layerwise ? ppw : 0;
+}
+
+hipError_t launch_conv3x3_body16w_chain(const ConvParams& p, const ChainArgs& c, int feat, hipStream_t stream, int ablate) {
+  if (!p.wpk || !p.bias || !c.hi || !c.lo || !c.t || !c.out_f32) return hipErrorInvalidValue;
+#ifdef DSEN2_DIAG
+  if (ablate == 1024 && feat == 256) return launch_body16w_chain_one<128, 256, 1024>(p, c, stream);
+  if (ablate == 1027 && feat == 256) return launch_body16w_chain_one<128, 256, 1027>(p, c, stream);
+  if (ablate == 3 && feat == 256) return launch_body16w_chain_one<128, 256, 3>(p, c, stream);
+#endif
+  if (ablate != 0) return hipErrorInvalidValue;
+  if (feat == 128) return launch_body16w_chain_one<64, 128>(p, c, stream);
+  if (feat == 256) return launch_body16w_chain_one<128, 256>(p, c, stream);
+  return hipErrorInvalidValue;
 }
 
 template <int F>

@@ -56,6 +56,7 @@ struct Tuning {
                            // 0 = padded 32-wide MFMA block (conv3x3_mfma.hip, the reference structure)
   int ablate = 0;          // timing-only ablation mask of the persistent body kernels (DSEN2_DIAG builds; wrong outputs)
   int grid_cap = 0;        // DSEN2_DIAG builds: launch at most this many workgroups of the bf16 body kernel (0 = one per CU)
+  int chain = 1;           // precision 1: one persistent launch over all body layers when the batch gives every CU whole patches
 };
 
 // Per-kernel launch preparation: the dynamic-LDS attribute is a property of (kernel, device) and is set once per pair,
@@ -107,6 +108,23 @@ void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, in
 // stream as two blocked 16-bit tensors p.aux (hi = bf16 rounding, the next operand) / p.out2 (lo), updated in place.
 // kEpiResidualF32: same inputs, result to p.out as fp32 NHWC (last block).  `ablate` != 0 only in DSEN2_DIAG builds.
 hipError_t launch_conv3x3_body16w(const ConvParams& p, int feat, int epilogue, int ablate, hipStream_t stream, int grid_cap = 0);
+// One launch over all 2d residual-block convolutions of a precision-1 network (conv3x3_body16w.hip, CHAIN): a workgroup
+// owns whole patches through every layer, so layers need no cross-workgroup synchronisation.
+struct ChainArgs {
+  void* hi;                   // residual stream: bf16 rounding plane (the convolutions' operand) ...
+  void* lo;                   // ... and low halves
+  void* t;                    // relu(conv-A), bf16 blocked
+  float* out_f32;             // last block's output, fp32 NHWC
+  unsigned layer_stride;      // bytes between the packed weights (and between the biases) of consecutive body layers
+  int n_layers;               // 2 * d
+  int patches_per_wg;
+};
+// p.wpk / p.bias = the first body layer's packed weights / bias (the following layers' lie layer_stride bytes further
+// each); p.n, p.h, p.w, p.res_scale as usual; the tensors come from `c`.  c.patches_per_wg is filled in here.
+hipError_t launch_conv3x3_body16w_chain(const ConvParams& p, const ChainArgs& c, int feat, hipStream_t stream, int ablate = 0);
+// > 0: the chain kernel keeps every CU as busy as the per-layer launches do for this batch (that many patches per
+// workgroup); 0: use the per-layer kernels
+int body16w_chain_patches_per_wg(int n, int h, int w, int feat, int cus);
 // fp32 NHWC tensor <-> blocked (hi, lo) tensors: hi = (u + 0x8000) >> 16, lo = u & 0xffff per value (c % 8 == 0)
 hipError_t launch_split_f32(const float* in_nhwc, void* hi, void* lo, int n, int h, int w, int c, hipStream_t stream);
 hipError_t launch_join_f32(const void* hi, const void* lo, float* out_nhwc, int n, int h, int w, int c, hipStream_t stream);
