@@ -7,7 +7,7 @@ the two translation units to ISA with exactly the product's flags and fails (Asm
   * every mention of M0 belongs to a DMA statement, which saves M0, sets it, waits one state, issues
     `buffer_load_dwordx4 ... lds` and restores M0 (hipcc reserves M0 and refuses it in a clobber list, so the
     statements preserve it themselves);
-  * every `buffer_load_dwordx4 ... lds` is one of those statements;
+  * every `buffer_load_dword[x4] ... lds` is one of those statements;
   * no kernel spills (a scratch access is a vector-memory operation: hipcc waits for a reload with vmcnt(0), which
     drains the DMA queue, and it is not in the hand counts) — the chain kernel (one launch over all body layers, three
     epilogue forms in one kernel) may spill a few values ACROSS its item loops, i.e. at a layer boundary where the
@@ -66,7 +66,7 @@ def check_listing(text, src):
 
     m0 = [i for i, ln in enumerate(code) if re.search(r'\bm0\b', ln)]
     need(m0, 'no M0 use found (the DMA statements are gone?)')
-    dma = [i for i, ln in enumerate(code) if ln.startswith('buffer_load_dwordx4') and ln.endswith('lds')]
+    dma = [i for i, ln in enumerate(code) if ln.startswith('buffer_load_dword') and ln.endswith('lds')]    # dwordx4, and dword (the chain's bias)
     need(dma, 'no LDS-DMA instruction found')
     allowed = set()
     for i in dma:
@@ -92,7 +92,7 @@ def check_listing(text, src):
     need(kernels, 'no kernel found')
     n_dma_kernels = 0
     for name, body in kernels.items():
-        if not any(ln.startswith('buffer_load_dwordx4') and ln.endswith('lds') for ln in body):
+        if not any(ln.startswith('buffer_load_dword') and ln.endswith('lds') for ln in body):
             continue                       # a kernel without LDS-DMA (the split / join helpers)
         n_dma_kernels += 1
         chain = '_chain_kernel' in name

@@ -309,9 +309,12 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
     if (m->chain_stride != 0 && m->tune.chain && m->tune.grid_cap == 0) {
       const Layer& L1 = m->layers[li];
       ConvParams pc = make_params(nullptr, P + L1.w_off, P + L1.b_off, nullptr, nullptr, n, h, w, 0, 0.1f);
+#ifdef DSEN2_DIAG
+      pc.diag = g_diag_stamps;
+#endif
       ChainArgs ca;
       ca.hi = hi; ca.lo = lo; ca.t = tbf; ca.out_f32 = a;
-      ca.layer_stride = (unsigned)m->chain_stride; ca.n_layers = 2 * m->num_layers; ca.patches_per_wg = 0;
+      ca.layer_stride = (unsigned)m->chain_stride; ca.n_layers = 2 * m->num_layers; ca.patches_per_wg = 0; ca.seamless = 0;
       chained = launch_conv3x3_body16w_chain(pc, ca, m->feat, stream, m->tune.ablate);
       if (chained == hipSuccess) li += 2 * (size_t)m->num_layers;
       else if (chained != hipErrorNotSupported) return fail(DSEN2_ERR_HIP, "chain kernel launch: %s", hipGetErrorString(chained));

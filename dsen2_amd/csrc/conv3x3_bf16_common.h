@@ -28,6 +28,13 @@ __device__ __forceinline__ void lds_dma(unsigned m0v, unsigned voff, __amdgpu_bu
                : "=&s"(saved_m0) : "s"(m0v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
+// One dword per lane (256 B per wave instruction, LDS address = m0v + 4 * lane): small tables such as a layer's bias.
+__device__ __forceinline__ void lds_dma_dword(unsigned m0v, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+  unsigned saved_m0;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(saved_m0) : "s"(m0v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 // The same for lanes 0-15 only (the 16-slot tail of a 336-slot row): EXEC is narrowed and restored INSIDE the
 // statement, so the compiler sees no divergent branch (a branch would cut the nine-step body into basic blocks).
 __device__ __forceinline__ void lds_dma_low16(unsigned m0v, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {

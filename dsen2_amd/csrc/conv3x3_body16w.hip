@@ -57,12 +57,13 @@ constexpr int THREADS = 512;                // 8 waves: (channel half) x (pixel 
 constexpr int MB = 4, PB = 8;               // per wave: 4 x 16 channels, 8 x 16 pixels (8 rows of one 16-column half)
 constexpr int XR = PB + 2;                  // halo-row fragments kept per dx
 constexpr size_t LDS_BYTES = (size_t)2 * IN_BYTES + (size_t)RING * WCH_BYTES + 256 * 4;
+constexpr size_t LDS_BYTES_CHAIN = LDS_BYTES + 256 * 4;     // the chain kernel double-buffers the bias
 // Cache policy of the once-per-block residual traffic (hi and lo loads, lo stores): nt (aux bit 1).  The stream is as
 // large as the Infinity Cache and each value is touched once per block; same-box A/B on the VDSen2 bf16 bench:
 // 16.03 k -> 16.39 k patches/s.  The hi stores keep the default policy: the next convolution reads them at once.
 constexpr int kResPolicy = 2;
 static_assert(QS >= HALO && QS % 16 == 0 && QS == 64 * IN_ROUNDS, "input chunk geometry");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(LDS_BYTES_CHAIN <= 160 * 1024, "LDS budget");
 
 // ISSUING WAVES.  Waves w and w + 4 share a SIMD.  A DMA costs its wave address arithmetic plus ~100 cycles of issue,
 // and a wave in that phase issues no MFMAs; with every wave issuing its share right after the barrier, both waves
@@ -107,10 +108,21 @@ constexpr int younger_than_input(bool has_w) { return has_w ? 4 * W_PER_STEP : 0
 // CHAIN (conv3x3_body16w_chain_kernel): ONE launch runs all 2d residual-block convolutions of a precision-1 network.
 // A workgroup owns whole patches — every item of `patches_per_wg` consecutive images, layer after layer — so a layer's
 // input was written by the same workgroup: no flag, no grid barrier, no cross-XCD visibility question; between two
-// layers the workgroup drains its own stores (vmcnt(0) + barrier: workgroup-scope release / acquire on one CU) and
-// stages the next layer's first input chunk.  The weight stream runs across the layer boundary (the packed weights of
-// consecutive body layers are `layer_stride` bytes apart in one buffer), so the ring is already full when a layer
-// starts.  EPI is then chosen per layer: conv-A (even) kEpiRelu hi -> t, conv-B (odd) kEpiResidual in place on
+// layers the workgroup only has to see its OWN stores (workgroup-scope release / acquire on one CU: a retired store
+// is visible to every later load of the same CU).  The weight stream runs across the layer boundary (the packed
+// weights of consecutive body layers are `layer_stride` bytes apart in one buffer), so the ring is always full.
+// Two forms of the boundary:
+//   * SEAMLESS (chain.seamless): the item loop just goes on — the last item of layer l stages chunk 0 of layer l+1's
+//     first item like any next item's, the next bias arrives by LDS-DMA in the other half of a double buffer.  Valid
+//     when no item reads what the item right before it in the workgroup's order wrote, except through input chunks
+//     >= 4: an item's outputs are retired by every wave by the end of the NEXT item's chunk 2 (issuing waves: their
+//     in-order counted waits, from chunk 0 on; compute-only waves: one vmcnt(0) there) and published by that step's
+//     barrier — before chunk 3 stages chunk 4, and long before the last chunk stages the following item's chunk 0.  True
+//     for >= 2 patches per workgroup (a patch's items of consecutive layers are then >= 2 positions apart) and for one
+//     patch per workgroup at F = 256 (the only distance-1 pair is last item = (last tile, slab 1) -> first item, and
+//     slab 1 is input chunks 4-7).  The alternative costs 14 us per layer: the exposed drain of an epilogue.
+//   * DRAINED otherwise (F = 128 with one patch per workgroup): every wave retires everything (vmcnt(0)), barrier, the
+//     next layer's first input chunk is staged and awaited.  EPI is then chosen per layer: conv-A (even) kEpiRelu hi -> t, conv-B (odd) kEpiResidual in place on
 // (hi, lo), the last one kEpiResidualF32 -> out_f32.  Same arithmetic per item as the per-layer kernels: same bits.
 
 template <int ABL>
@@ -177,6 +189,11 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
     return Tile{img, tyi * TH, (trem - tyi * TX_) * TW, item - tile * NS};
   };
 
+  // CHAIN: state of the current layer (set by the layer loop at the end of this function)
+  float* bias_cur = bias_s;                 // LDS: the bias the accumulators start from ([2][COUT] in a chain)
+  int ly_more = 0, ly_seamless = 0;         // another layer follows / its boundary is seamless
+  unsigned bias_next_lds = 0, bias_next_so = 0;   // where the NEXT layer's bias goes (LDS byte address) / comes from (offset in w_rsrc)
+
   // The tensors of a convolution.  Per-layer kernel: the launch's parameters.  CHAIN: a function of the layer's
   // epilogue only (conv-A hi -> t; conv-B t -> (hi, lo) in place, or -> out_f32 for the last one), i.e. kernel arguments
   // inside each instantiation of the item loop — nothing per layer has to live in registers across it.
@@ -198,7 +215,7 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
   __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, 0, 0x00020000);   // set per staged item
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.wpk), 0,
-      (unsigned)(NS * NCHUNK * WCH_BYTES) + (CHAIN ? (unsigned)(chain.n_layers - 1) * chain.layer_stride : 0u), 0x00020000);
+      CHAIN ? (unsigned)chain.n_layers * chain.layer_stride : (unsigned)(NS * NCHUNK * WCH_BYTES), 0x00020000);
   unsigned in_plane_bytes = (unsigned)(IMGPIX_ * 16);   // one 8-channel block of one image
   int st_y0 = 0, st_x0 = 0;                        // origin of the tile being staged
   auto set_stage_item = [&](auto epi_c, int item) __attribute__((always_inline)) {
@@ -269,13 +286,9 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
   // CHAIN the same statement is what makes layer l's outputs (this workgroup's own stores) the input of layer l + 1:
   // every wave retires its stores (vmcnt(0)), the barrier orders them before the issuing waves' DMA reads.
   auto begin_layer = [&](auto epi_c, const float* bias) __attribute__((always_inline)) {
-    if constexpr (CHAIN && (ABL & 1024) != 0) return;      // diagnostic mask 1024 (timing only): layers follow each other with no boundary at all
     if constexpr (CHAIN) {
       wait_vmcnt<0>();
       __syncthreads();
-      // (two statements: hipcc treats EVERY output of an asm statement as divergent when one of them is a VGPR)
-      asm volatile("" : "+s"(W_), "+s"(H_), "+s"(TX_), "+s"(TPI_), "+s"(RS_), "+s"(IMGPIX_), "+s"(in_plane_bytes));
-      asm volatile("" : "+v"(l15), "+v"(q4));
     }
     set_stage_item(epi_c, item0);
     if (wave < 4) {
@@ -285,9 +298,11 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
       }
     }
     if constexpr (CHAIN) {
-      int t = tid;                    // opaque copy: the LDS address is computed here, not kept (spilled) across the layers
-      asm volatile("" : "+v"(t));
-      if (t < COUT) bias_s[t] = bias[t];
+      if (bias) {                     // the first layer's; every later one arrives by DMA during the layer before it
+        int t = tid;                  // opaque copy: the LDS address is computed here, not kept (spilled) across the layers
+        asm volatile("" : "+v"(t));
+        if (t < COUT) bias_s[t] = bias[t];
+      }
     } else {
       if (tid < COUT) bias_s[tid] = p.bias[tid];
     }
@@ -324,6 +339,16 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
       if (p.diag && lid < 4 && (wave == 0 || wave == 7) && lane == 0)
         p.diag[(((size_t)lid * 2 + (wave == 7)) * 16 + (stamp_it & 15)) * 32 + k] =
             k == 19 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();      // slot 19: the 100 MHz counter
+    }
+  };
+
+  // diagnostic mask 4096 (chain kernel): s_memtime of waves 0 and 7 of the first four workgroups at every item-loop top
+  // (k = 0) and after every epilogue (k = 1): slot [workgroup][wave 0 / 7][layer][iteration 0..7][k]
+  int stamp_layer = 0;
+  auto stampc = [&](int k) __attribute__((always_inline)) {
+    if constexpr (CHAIN && (ABL & 4096) != 0) {
+      if (p.diag && lid < 4 && (wave == 0 || wave == 7) && lane == 0 && stamp_it < 8 && stamp_layer < 64)
+        p.diag[((((size_t)lid * 2 + (wave == 7)) * 64 + stamp_layer) * 8 + stamp_it) * 2 + k] = __builtin_amdgcn_s_memtime();
     }
   };
 
@@ -474,6 +499,10 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
   auto run = [&](auto issuer_c, auto epi_c) __attribute__((always_inline)) {
   constexpr bool ISSUER = decltype(issuer_c)::value;
   constexpr int E_OPS = epilogue_ops<ABL>(decltype(epi_c)::value);
+  // CHAIN: the layer before / after this one (conv-A and conv-B alternate); what is still in flight when a layer's
+  // FIRST item starts is the other kind's epilogue — its waits may count no more than the smaller of the two
+  constexpr int EPI_OTHER = decltype(epi_c)::value == kEpiRelu ? kEpiResidual : kEpiRelu;
+  constexpr int E_FIRST = !CHAIN || epilogue_ops<ABL>(EPI_OTHER) > E_OPS ? E_OPS : epilogue_ops<ABL>(EPI_OTHER);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -486,9 +515,11 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
     // (CHAIN: no dummy epilogue before a layer's first item — begin_layer has retired everything older than the
     // item's own DMAs, so the first-chunk waits, which count E_OPS operations that are then not there, have nothing
     // older left to protect)
+    stampc(0);
     if (!CHAIN || it > 0) epilogue(epi_c, it > 0 ? item0 + (it - 1) * istep : item0, it > 0);
     __builtin_amdgcn_sched_barrier(0);
     stamp(1);
+    stampc(1);
     if (it == my_items) break;
     const int item = item0 + it * istep;
     const bool have_next_item = it + 1 < my_items;
@@ -497,7 +528,7 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
       const int ch8 = (item % NS) * 128 + wn * 64 + 8 * q4;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + ch8 + 32 * (mb >> 1) + 4 * (mb & 1));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias_cur + ch8 + 32 * (mb >> 1) + 4 * (mb & 1));
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) acc[mb][pb] = b;
       }
@@ -513,6 +544,11 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
     // and step 1's weight DMA reuses chunk 0's ring slot with no barrier after step 0: synchronise here, once per item.
     if constexpr (!(ABL & 16)) __syncthreads();
     stamp(2);
+    if constexpr (CHAIN) {
+      // the next layer's bias into the other half of the double buffer (read two hundred steps from now)
+      if (ISSUER && it == 0 && ly_more != 0 && wave < COUT / 64) lds_dma_dword(bias_next_lds, lane * 4, w_rsrc, bias_next_so);
+    }
+    const int first_item = __builtin_amdgcn_readfirstlane(it == 0 ? 1 : 0);   // an SGPR for the asm statements below
 
     // ONE copy of the nine-step body for every input chunk (a separate copy for the item's first chunk makes the
     // register allocator permute all 32 accumulators between the two copies and spill); the first chunk's five
@@ -524,7 +560,12 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
       // very last item: its own chunk 0 again, which nobody reads — the operation count stays the same)
       const bool last_cc = cc == NCC - 1;
       const int in_cc = last_cc ? 0 : cc + 1;
-      if (ISSUER && last_cc && have_next_item) set_stage_item(epi_c, item + istep);
+      if (ISSUER && last_cc) {
+        if (have_next_item) set_stage_item(epi_c, item + istep);
+        else if constexpr (CHAIN) {       // seamless boundary: chunk 0 of the next layer's first item
+          if (ly_seamless != 0 && ly_more != 0) set_stage_item(std::integral_constant<int, EPI_OTHER>{}, item0);
+        }
+      }
       auto step = [&](auto st_c) __attribute__((always_inline)) {
         constexpr int st = decltype(st_c)::value;        // index of the step inside its chunk
         const int nx_slot = mf_slot == RING - 1 ? 0 : mf_slot + 1;
@@ -579,7 +620,15 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
             constexpr int kN0 = younger_ops(st, kD, kW, kIn);
             constexpr int kN = (st == 7 && kIn && younger_than_input(kW) < kN0) ? younger_than_input(kW) : kN0;
             constexpr int kNE = kN + E_OPS < 63 ? kN + E_OPS : 63;
-            if constexpr (st + kD < LEAD && kNE != kN) {
+            constexpr int kNF = kN + E_FIRST < 63 ? kN + E_FIRST : 63;
+            if constexpr (st + kD < LEAD && kNE != kN && kNF != kNE) {
+              // CHAIN, a layer's first item: the epilogue in flight is the previous layer's (fewer operations)
+              asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc0 .Ldsen2_n%=\n\ts_cmp_eq_u32 %1, 0\n\ts_cbranch_scc1 .Ldsen2_w%=\n\t"
+                           "s_waitcnt vmcnt(%4)\n\ts_branch .Ldsen2_e%=\n"
+                           ".Ldsen2_w%=:\n\ts_waitcnt vmcnt(%3)\n\ts_branch .Ldsen2_e%=\n"
+                           ".Ldsen2_n%=:\n\ts_waitcnt vmcnt(%2)\n.Ldsen2_e%=:"
+                           ::"s"(cc), "s"(first_item), "n"(kN), "n"(kNE), "n"(kNF) : "memory", "scc");
+            } else if constexpr (st + kD < LEAD && kNE != kN) {
               // vmcnt(kNE) in the item's first chunk, vmcnt(kN) otherwise.  The scalar branch lives inside ONE asm
               // statement so that the nine-step body stays a single basic block (split into blocks, hipcc's register
               // allocator shuffles the accumulators between them and spills into the DMA-counted vmcnt stream).
@@ -589,6 +638,12 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
             } else {
               wait_vmcnt<kN>();
             }
+          }
+          if constexpr (CHAIN && !ISSUER && st == 8 && !(ABL & 2048)) {
+            // compute-only waves never wait on vmcnt; in a chain their stores are the next layer's input, so once per
+            // item — at the end of its chunk 2 — they retire the previous item's epilogue (issued 27 steps ago).
+            // (diagnostic mask 2048, timing only: without this wait)
+            asm volatile("s_cmp_eq_u32 %0, 2\n\ts_cbranch_scc0 .Ldsen2_k%=\n\ts_waitcnt vmcnt(0)\n.Ldsen2_k%=:" ::"s"(cc) : "memory", "scc");
           }
           if constexpr (!(ABL & 16)) __syncthreads();
         }
@@ -618,11 +673,23 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
     else
       run(std::false_type{}, std::integral_constant<int, EPI0>{});
   } else {
+    const unsigned lds_bias = lds_address(bias_s);
+    const unsigned bias_delta = (unsigned)(reinterpret_cast<const char*>(p.bias) - reinterpret_cast<const char*>(p.wpk));
+    ly_seamless = (ABL & 1024) ? 0 : chain.seamless;      // diagnostic mask 1024: drained boundaries even where seamless ones are valid (A/B)
 #pragma unroll 1
     for (int l = 0; l < chain.n_layers; ++l) {
-      const float* const bias = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.bias) + (size_t)l * chain.layer_stride);
+      // Layer-invariant values pass through an empty asm statement at the start of every layer (see their definition).
+      // (two statements: hipcc treats EVERY output of an asm statement as divergent when one of them is a VGPR)
+      asm volatile("" : "+s"(W_), "+s"(H_), "+s"(TX_), "+s"(TPI_), "+s"(RS_), "+s"(IMGPIX_), "+s"(in_plane_bytes));
+      asm volatile("" : "+v"(l15), "+v"(q4));
+      stamp_layer = l;
+      ly_more = l + 1 < chain.n_layers ? 1 : 0;
+      bias_cur = bias_s + (l & 1) * COUT;
+      bias_next_lds = lds_bias + (unsigned)(((l + 1) & 1) * COUT * 4 + wave * 256);
+      bias_next_so = bias_delta + (unsigned)(l + 1) * chain.layer_stride + (unsigned)(wave * 256);
       auto layer = [&](auto epi_c) __attribute__((always_inline)) {
-        begin_layer(epi_c, bias);
+        if (l == 0) begin_layer(epi_c, p.bias);
+        else if (ly_seamless == 0) begin_layer(epi_c, nullptr);
         if (wave < 4) run(std::true_type{}, epi_c);
         else run(std::false_type{}, epi_c);
       };
@@ -669,18 +736,23 @@ static hipError_t launch_body16w_chain_one(ConvParams p, ChainArgs c, hipStream_
   auto kern = conv3x3_body16w_chain_kernel<CINW, COUT, ABL>;
   static KernelOnce once;
   int cus = 0;
-  hipError_t e = once.prepare(reinterpret_cast<const void*>(kern), LDS_BYTES, &cus);
+  hipError_t e = once.prepare(reinterpret_cast<const void*>(kern), LDS_BYTES_CHAIN, &cus);
   if (e != hipSuccess) return e;
   if ((size_t)p.h * p.w * COUT >= ((size_t)1 << 29)) return hipErrorInvalidValue;
   p.tiles_x = (p.w + TW - 1) / TW;
   p.tiles_y = (p.h + TH - 1) / TH;
+  // a layer = its packed weights, then (within layer_stride) its bias: the kernel addresses both through one descriptor
+  const long long bias_delta = reinterpret_cast<const char*>(p.bias) - reinterpret_cast<const char*>(p.wpk);
+  if (bias_delta < (long long)(COUT / 128) * (CINW / 16) * 9 * WCH_BYTES || bias_delta + COUT * 4 > (long long)c.layer_stride)
+    return hipErrorInvalidValue;
   c.patches_per_wg = body16w_chain_patches_per_wg(p.n, p.h, p.w, COUT, cus);
   if (c.n_layers <= 0) return hipErrorInvalidValue;
   if (c.patches_per_wg <= 0) return hipErrorNotSupported;       // the per-layer kernels keep more CUs busy for this batch
   // the weight descriptor spans all layers: 32-bit byte offsets
   if ((unsigned long long)c.n_layers * c.layer_stride >= 0xffffffffull) return hipErrorInvalidValue;
   const int grid = (p.n + c.patches_per_wg - 1) / c.patches_per_wg;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, stream, p, c);
+  c.seamless = (c.patches_per_wg >= 2 || COUT == 256) ? 1 : 0;     // see the kernel's header: when no drain is needed
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES_CHAIN, stream, p, c);
   return hipGetLastError();
 }
 
@@ -698,7 +770,10 @@ hipError_t launch_conv3x3_body16w_chain(const ConvParams& p, const ChainArgs& c,
   if (!p.wpk || !p.bias || !c.hi || !c.lo || !c.t || !c.out_f32) return hipErrorInvalidValue;
 #ifdef DSEN2_DIAG
   if (ablate == 1024 && feat == 256) return launch_body16w_chain_one<128, 256, 1024>(p, c, stream);
-  if (ablate == 1027 && feat == 256) return launch_body16w_chain_one<128, 256, 1027>(p, c, stream);
+  if (ablate == 1024 && feat == 128) return launch_body16w_chain_one<64, 128, 1024>(p, c, stream);
+  if (ablate == 2048 && feat == 256) return launch_body16w_chain_one<128, 256, 2048>(p, c, stream);
+  if (ablate == 4096 && feat == 256) return launch_body16w_chain_one<128, 256, 4096>(p, c, stream);
+  if (ablate == 5120 && feat == 256) return launch_body16w_chain_one<128, 256, 5120>(p, c, stream);
   if (ablate == 3 && feat == 256) return launch_body16w_chain_one<128, 256, 3>(p, c, stream);
 #endif
   if (ablate != 0) return hipErrorInvalidValue;

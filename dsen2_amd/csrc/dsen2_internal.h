@@ -118,6 +118,7 @@ struct ChainArgs {
   unsigned layer_stride;      // bytes between the packed weights (and between the biases) of consecutive body layers
   int n_layers;               // 2 * d
   int patches_per_wg;
+  int seamless;               // layer boundaries without a drain (conv3x3_body16w.hip; filled in by the launcher)
 };
 // p.wpk / p.bias = the first body layer's packed weights / bias (the following layers' lie layer_stride bytes further
 // each); p.n, p.h, p.w, p.res_scale as usual; the tensors come from `c`.  c.patches_per_wg is filled in here.
