@@ -171,7 +171,7 @@ def test_demo_script_prints_a_parity_rmse():
     assert 'Super-resolving the 60m data into 10m bands' in p.stdout and 'sr20 (264, 264, 6) float32' in p.stdout
 
 
-BF16_GATE_REL = 1e-2        # rmse / signal rms in the normalised domain (tests/test_gpu_vdsen2_bf16.py)
+BF16_GATE_REL = 5e-3        # rmse / signal rms in the normalised domain: 1.8x the 2.8e-3 measured at d=32 (profiles)
 
 
 def test_dsen2_20_and_60_in_bf16_through_the_drop_in_surface(model_dir, monkeypatch):
