@@ -108,6 +108,10 @@ int dsen2_diag_set(int key, int value) {
     g_diag_tuning.grid_cap = value;
     return DSEN2_OK;
   }
+  if (key == 5) {   // timing-only ablation mask of the first convolution (1 no stores, 2 no MFMAs, 4 no gather)
+    g_diag_tuning.first_ablate = value;
+    return DSEN2_OK;
+  }
   if (key == 4) {   // 0 = always launch the bf16 body convolutions layer by layer (A/B against the chain kernel)
     g_diag_tuning.chain = value;
     return DSEN2_OK;
@@ -280,11 +284,10 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
   const float* skip = m->c60 > 0 ? x60 : x20;    // utils/DSen2Net.py:38,41
 
   const int abl = m->tune.ablate;
-  HIP_TRY(launch_pack_inputs(x10, x20, x60, m->c10, m->c20, m->c60, x0, n, h, w, stream));
   size_t li = 0;
   const bool planes = m->precision == 1 && m->num_layers > 0;
   {
-    const Layer& L = m->layers[li++];            // DSen2Net.py:29
+    const Layer& L = m->layers[li++];            // DSen2Net.py:24-29: Concatenate + Conv2D + ReLU
     ConvParams pf = make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f);
     if (planes) {
       // a precision-1 model's first convolution writes the residual stream directly as its two blocked 16-bit planes
@@ -292,7 +295,23 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
       pf.out = t;
       pf.out2 = t + half;
     }
-    HIP_TRY(launch_conv3x3(pf, L.geom, planes ? (int)kEpiReluSplit : L.epilogue, 0, stream));
+    const int epi0 = planes ? (int)kEpiReluSplit : L.epilogue;
+    // the default structure reads the NCHW inputs itself (conv3x3_first.hip); other channel counts, and the reference
+    // structure (variant 0), pack them to NHWC16 first
+    hipError_t direct = hipErrorNotSupported;
+    if (L.geom.variant == 10 || L.geom.variant == 12) {
+      ConvParams pd = pf;
+      pd.in = x10;
+      pd.aux = x20;
+      const FirstInputs fi{x60, m->c10, m->c20, m->c60};
+      direct = launch_conv3x3_first(pd, fi, m->feat, epi0, stream, m->tune.first_ablate);
+      if (direct != hipSuccess && direct != hipErrorNotSupported)
+        return fail(DSEN2_ERR_HIP, "first convolution launch: %s", hipGetErrorString(direct));
+    }
+    if (direct != hipSuccess) {
+      HIP_TRY(launch_pack_inputs(x10, x20, x60, m->c10, m->c20, m->c60, x0, n, h, w, stream));
+      HIP_TRY(launch_conv3x3(pf, L.geom, epi0, 0, stream));
+    }
   }
   if (planes) {
     // bf16 operands, fp32 accumulate, exact fp32 residual stream held as two 16-bit planes (hi = the bf16 operand of

@@ -56,6 +56,7 @@ struct Tuning {
                            // 0 = padded 32-wide MFMA block (conv3x3_mfma.hip, the reference structure)
   int ablate = 0;          // timing-only ablation mask of the persistent body kernels (DSEN2_DIAG builds; wrong outputs)
   int grid_cap = 0;        // DSEN2_DIAG builds: launch at most this many workgroups of the bf16 body kernel (0 = one per CU)
+  int first_ablate = 0;    // DSEN2_DIAG builds: timing-only ablation mask of the first convolution (conv3x3_first.hip)
   int chain = 1;           // precision 1: one persistent launch over all body layers when the batch gives every CU whole patches
 };
 
@@ -94,6 +95,11 @@ hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogu
 // pack_out_valu_weights_host)
 hipError_t launch_conv3x3_out_valu(const ConvParams& p, int feat, hipStream_t stream);
 void pack_out_valu_weights_host(const float* kernel_hwio, int cin, int cout, float* dst);
+// First convolution reading the NCHW inputs directly (conv3x3_first.hip): p.in = x10, p.aux = x20; weights packed with
+// PackGeom{16, 128, 16, cout, .}; epilogue kEpiRelu (p.out fp32 NHWC) or kEpiReluSplit (p.out / p.out2 = (hi, lo) planes).
+// hipErrorNotSupported for channel counts other than 10 / 12 (then: launch_pack_inputs + launch_conv3x3).
+struct FirstInputs { const float* x60; int c10, c20, c60; };
+hipError_t launch_conv3x3_first(const ConvParams& p, const FirstInputs& f, int cout, int epilogue, hipStream_t stream, int ablate = 0);
 // DMA-fed fp32 kernel (conv3x3_body32.hip): F = 128 or 256, images < 2 GiB; weights packed with KC=32, NT=128
 bool body32_supports(const ConvParams& p, int cout);
 hipError_t launch_conv3x3_body32(const ConvParams& p, int feat, int epilogue, int sub, int ablate, hipStream_t stream);
