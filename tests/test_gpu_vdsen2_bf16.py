@@ -125,3 +125,31 @@ def test_dsen2_60_batch_512_properties():
     idx = [0, 31, 256, 511]
     ref = c_oracle.forward([a[idx] for a in xs], flat, 6, 128)
     assert do.rmse(y[idx], ref) < 5e-6
+
+
+@pytest.mark.parametrize('feat,d,n,h,w', [
+    (256, 2, 256, 32, 32),      # configs[4]'s geometry: one patch per workgroup, seamless boundaries (slab 1 = input chunks 4-7)
+    (256, 1, 512, 32, 32),      # two patches per workgroup
+    (256, 2, 256, 16, 32),      # one tile per patch: the only items of a layer are the two slabs
+    (256, 1, 256, 48, 40),      # 3 x 2 tiles per patch, ragged last column
+    (128, 3, 256, 32, 32),      # F = 128, one patch per workgroup: DRAINED boundaries (a tile reads its neighbour's chunk 0)
+    (128, 2, 512, 32, 32),      # F = 128, two patches per workgroup: seamless
+    (128, 2, 300, 16, 32),      # uneven: the last workgroups own one patch, the others two
+])
+def test_chain_kernel_equals_the_per_layer_kernels_bit_for_bit(feat, d, n, h, w):
+    """precision 1: a batch that gives every CU whole patches runs its 2d body convolutions as ONE chain launch
+    (conv3x3_body16w.hip, CHAIN); a 5-patch sub-batch of the same inputs runs layer by layer.  Same arithmetic per item,
+    so the chain's outputs for those patches must be the per-layer kernels' bits — for every form of the layer
+    boundary (seamless with one or several patches per workgroup, drained) and for ragged / single-tile patches."""
+    flat = do.he_uniform_weights(10, 6, d, feat, seed=d + feat + n, bias_scale=0.05)
+    rng = np.random.Generator(np.random.PCG64(n + h))
+    xs = [rng.random((n, c, h, w), dtype=np.float32) * np.float32(5.0) for c in (4, 6)]
+    m = _model(BANDS20, d, feat, flat, 'bf16')
+    dev = [torch.from_numpy(a).cuda() for a in xs]
+    y = m.forward_device(dev)
+    for first in (0, n // 2 - 2, n - 5):
+        sub = m.forward_device([t[first:first + 5].contiguous() for t in dev])
+        assert torch.equal(sub, y[first:first + 5]), (feat, d, n, h, w, first)
+    ref = c_oracle.forward([a[:2] for a in xs], flat, d, feat)
+    _, rel, _ = _errors(y[:2].cpu().numpy(), ref)
+    assert rel < BF16_GATE_REL
