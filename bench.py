@@ -176,6 +176,10 @@ def main():
         ms_relu = model.time_body_conv(1, a, None, o, iters=10)          # conv-A (+bias+ReLU)
         ms_res = model.time_body_conv(2, a, r, o, iters=10)              # conv-B (+bias, *0.1, +residual)
         flops = pix * FLOP_PER_PIXEL_BODY
+        # the dominant kernel: one launch per body convolution, or (bf16, a batch of whole patches per CU) ONE chain
+        # launch over all 2d of them — then a launch's work and duration are 2d layers'
+        launches = model.body_launches(args.batch, H, W)
+        per_launch = 2 * NUM_LAYERS // launches
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, 'profiles', 'body_conv_traffic.json')
         if os.path.exists(tj) and args.batch == BATCH:
@@ -187,12 +191,15 @@ def main():
                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK, 4), 'traffic': traffic,
                               'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
                               'traffic_source': traffic_src,
-                              'kernel': '%s (3x3x%dx%d, %s, persistent)' % (
-                                  'conv3x3_body16w_kernel' if bf else 'conv3x3_body32_kernel',
-                                  FEAT, FEAT, 'bf16 MFMA 16x16x32, LDS-DMA staging, 16x32-pixel items' if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging'),
-                              'ms_per_launch': round(ms, 4), 'ms_per_launch_source': 'HIP events around the %d body-conv launches of %d forward passes' % (2 * NUM_LAYERS, args.steps),
+                              'kernel': '%s (3x3x%dx%d, %s, persistent%s)' % (
+                                  ('conv3x3_body16w_chain_kernel' if launches == 1 else 'conv3x3_body16w_kernel') if bf else 'conv3x3_body32_kernel',
+                                  FEAT, FEAT, 'bf16 MFMA 16x16x32, LDS-DMA staging, 16x32-pixel items' if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging',
+                                  '; ONE launch over all %d body convolutions, a workgroup owns its patches through every layer' % (2 * NUM_LAYERS) if launches == 1 else ''),
+                              'ms_per_launch': round(ms * per_launch, 4),
+                              'ms_per_launch_source': 'HIP events around the %d body-conv launch%s of %d forward passes' % (launches, '' if launches == 1 else 'es', args.steps),
+                              'launches_per_forward': launches, 'convolutions_per_launch': per_launch, 'ms_per_convolution': round(ms, 4),
                               'ms_relu_randn': round(ms_relu, 4), 'ms_residual_randn': round(ms_res, 4),
-                              'flop_per_launch': flops}
+                              'flop_per_launch': flops * per_launch}
         del a, r, o
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'dsen2_20_fp32':

@@ -137,6 +137,14 @@ class S2Model(object):
                       _ptr(ws), ws.numel(), _stream_ptr(self.device), int(iters), ctypes.byref(ms))
         return ms.value
 
+    def body_launches(self, n, h, w):
+        """Kernel launches the 2*num_layers residual-block convolutions of a batch take: 1 = one chain launch."""
+        with torch.cuda.device(self.device):
+            r = _lib.load().dsen2_model_body_launches(self._handle, int(n), int(h), int(w))
+        if r < 0:
+            raise _lib.DSen2Error(r, _lib.load().dsen2_last_error().decode())
+        return r
+
     def batch_limit(self, h, w):
         per = self.workspace_bytes(1, h, w)
         return max(1, int(self.max_workspace_bytes // per))

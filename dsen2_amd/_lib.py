@@ -30,6 +30,7 @@ SIGNATURES = {
     'dsen2_model_workspace_bytes': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     'dsen2_model_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                     c_void_p, c_size_t, c_void_p]),
+    'dsen2_model_body_launches': (c_int, [c_void_p, c_int, c_int, c_int]),
     'dsen2_model_forward_timed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_void_p, c_size_t, c_void_p, c_int, c_float_p]),
     'dsen2_conv3x3_nhwc': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

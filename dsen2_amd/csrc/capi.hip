@@ -368,6 +368,18 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
   return DSEN2_OK;
 }
 
+int dsen2_model_body_launches(const dsen2_model* m, int n, int h, int w) {
+  if (!m) return fail(DSEN2_ERR_INVALID, "NULL model");
+  int rc = check_shape(m, n, h, w);
+  if (rc) return rc;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return fail(DSEN2_ERR_NO_DEVICE, "no HIP device");
+  const bool chain = m->precision == 1 && m->num_layers > 0 && m->chain_stride != 0 && m->tune.chain && m->tune.grid_cap == 0 &&
+                     body16w_chain_patches_per_wg(n, h, w, m->feat, cus) > 0;
+  return chain ? 1 : 2 * m->num_layers;
+}
+
 int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
                         int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
   return forward_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, nullptr, nullptr);

@@ -73,10 +73,17 @@ int dsen2_model_forward(dsen2_model *m, const float *dev_x10, const float *dev_x
                         float *dev_out, int n, int h, int w, void *dev_workspace, size_t workspace_bytes,
                         void *stream);
 
+/* How many kernel launches the 2*num_layers residual-block convolutions of one forward of n patches of h x w take on
+ * the current device: 2*num_layers (one per convolution), or 1 — a precision-1 model runs them as ONE persistent
+ * "chain" launch when the batch gives every CU whole patches (each workgroup then owns its patches through all layers;
+ * e.g. 256 patches of 32x32 on 256 CUs).  Same results either way, bit for bit.  <0 on error. */
+int dsen2_model_body_launches(const dsen2_model *m, int n, int h, int w);
+
 /* Measurement hook (no reference counterpart): `iters` forward passes exactly as dsen2_model_forward enqueues them,
  * with a HIP event recorded on `stream` before the first and after the last residual-block convolution of each
- * pass.  *body_ms_per_launch = mean duration of ONE of those 2*num_layers convolution launches inside the running
- * network (bench.py's roofline figure).  Synchronises the stream. */
+ * pass.  *body_ms_per_launch = that interval / (2*num_layers): the mean duration of ONE of those convolutions inside
+ * the running network, whether they are 2*num_layers launches or one chain launch (bench.py's roofline figure).
+ * Synchronises the stream. */
 int dsen2_model_forward_timed(dsen2_model *m, const float *x10, const float *x20, const float *x60, float *out,
                               int n, int h, int w, void *workspace, size_t workspace_bytes, void *stream, int iters,
                               float *body_ms_per_launch);

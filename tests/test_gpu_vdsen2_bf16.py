@@ -146,6 +146,9 @@ def test_chain_kernel_equals_the_per_layer_kernels_bit_for_bit(feat, d, n, h, w)
     xs = [rng.random((n, c, h, w), dtype=np.float32) * np.float32(5.0) for c in (4, 6)]
     m = _model(BANDS20, d, feat, flat, 'bf16')
     dev = [torch.from_numpy(a).cuda() for a in xs]
+    assert m.body_launches(n, h, w) == 1                      # the whole batch: one chain launch
+    if h * w > 16 * 32:
+        assert m.body_launches(5, h, w) == 2 * d              # the sub-batch: layer by layer (several items per patch)
     y = m.forward_device(dev)
     for first in (0, n // 2 - 2, n - 5):
         sub = m.forward_device([t[first:first + 5].contiguous() for t in dev])
