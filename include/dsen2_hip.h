@@ -47,8 +47,10 @@ int dsen2_device_count(void);
  *   precision: 0 = fp32 everywhere (exact-f32 MFMA); 1 = bf16 operands for the residual-block convolutions
  *   (v_mfma_f32_16x16x32_bf16), fp32 accumulation, an exact fp32 residual stream (kept as two 16-bit planes, see
  *   dsen2_split_f32), fp32 first and last convolution.
- *   A model's kernel structures are fixed when it is created; the library has no process-global mutable state,
- *   so any number of handles (one per rank / device) coexist.
+ *   A model's kernel structures are fixed when it is created; the only process-global state of the library are
+ *   per-(kernel, device) launch attributes, set once under a mutex — any number of handles (one per rank / device)
+ *   coexist, and host threads may drive different devices, or one handle from several streams (each call with
+ *   its own workspace), concurrently.
  */
 int dsen2_model_create(dsen2_model **out, int c10, int c20, int c60, int num_layers, int feature_size,
                        int precision);
