@@ -39,3 +39,25 @@ def test_forward_is_bitwise_reproducible_across_launches():
         ref = m.forward_device(xs).clone()
         for _ in range(8):
             assert torch.equal(m.forward_device(xs), ref), prec
+
+
+@pytest.mark.parametrize('feat,d,n', [(256, 8, 256), (128, 4, 256), (128, 4, 512)])
+def test_chain_kernel_over_many_launches_on_fresh_data(feat, d, n):
+    """Race screen of the chain kernel's layer boundaries (seamless with one patch per workgroup at F = 256 and two at
+    F = 128, drained at F = 128 with one): the chain launch depends on hand-placed waits for its OWN stores between
+    layers, so a too-weak one shows up as a rare stale halo.  60 forwards on fresh random inputs each, every one
+    compared bit for bit with the same patches run layer by layer (sub-batches of 5: the per-layer kernels)."""
+    from dsen2_amd import weights as W
+    from dsen2_amd.DSen2Net import s2model
+    m = s2model(((4, None, None), (6, None, None)), num_layers=d, feature_size=feat, precision='bf16')
+    m.set_weights_flat(W.random_he_uniform(10, 6, d, feat, seed=feat + d, bias_scale=0.05))
+    assert m.body_launches(n, 32, 32) == 1 and m.body_launches(5, 32, 32) == 2 * d
+    gen = torch.Generator(device='cuda').manual_seed(n + feat)
+    bad = 0
+    for rep in range(60):
+        xs = [torch.rand((n, c, 32, 32), device='cuda', generator=gen) * 5 for c in (4, 6)]
+        y = m.forward_device(xs)
+        for first in (0, (37 * rep) % (n - 5), n - 5):
+            sub = m.forward_device([t[first:first + 5].contiguous() for t in xs])
+            bad += int((sub != y[first:first + 5]).sum())
+    assert bad == 0
