@@ -6,17 +6,17 @@
 // one 16x16-pixel tile per workgroup, the 72 KB of weights streamed from L2 for EVERY tile with a barrier per tap.
 // With K = 9 x 10 the layer has 77 us of MFMA work and 268 MB of output at the bench config: it is bound by how well
 // the two overlap, not by either.  This kernel:
-//   * is persistent (TWO workgroups of 8 waves per CU walk tiles lid, lid + G, ...): the weights of a workgroup's output
+//   * is persistent (one workgroup of 8 waves per CU walks tiles lid, lid + G, ...): the weights of the workgroup's output
 //     slab (the three k-groups the 10 / 12 real channels use: 54 KB) and the bias are copied to LDS ONCE, the tap loop
-//     has no barrier — two barriers per tile, around the refill of the single input buffer;
+//     has no barrier — one barrier per tile;
 //   * reads the NCHW inputs directly: the halo tile of the next item is gathered plane by plane (18-pixel row
-//     segments, coalesced) into registers while the current tile computes, then written to LDS in the MFMA's operand
-//     layout ([halo pixel][channel], 20-float pixel pitch) — the Concatenate is an address computation;
-//   * fires its 128 KB of stores per tile and goes on.
-// Measured at the bench config (rocprofv3, profiles/r03_ablation.md §3): 126 us against 127 + 18 for round 2's pair of
-// kernels; timing-only ablations: MFMA loop alone 97 us (of which 14 us are weights, barriers and epilogue arithmetic),
-// stores alone 47 us — the two phases of a tile do not overlap yet (both workgroups of a CU run them in lockstep; a
-// start offset for one of them did not stick), which is what separates this kernel from its 85-90 us floor.
+//     segments, coalesced) into registers while the current tile computes, then written to the other half of a double
+//     buffer in the MFMA's operand layout ([halo pixel][channel], 20-float pixel pitch) — the Concatenate is an address
+//     computation;
+//   * DEFERS its epilogue like the body kernel: a finished tile's accumulators are copied to a second register set and
+//     written out two 16-byte pieces per tap inside the NEXT tile's tap loop, so the 128 KB of stores per tile leave
+//     under MFMAs instead of in a phase of their own (measured before: MFMA loop alone 97 us, stores alone 47 us, the
+//     two in sequence 126 us — profiles/r03_d_first_conv_ablation.log).
 // The MFMA sequence per accumulator is exactly conv3x3_mfma_kernel's first-layer form (per tap: channels (j, 4 + j) for
 // j = 0..3, then the pairs (8, 9)(, (10, 11)); taps in order), so every output bit is the same
 // (tests/test_gpu_forward.py::test_first_layer_without_padding_mfmas_gives_the_same_bits pins it against the generic kernel).
@@ -39,8 +39,8 @@ constexpr int WCH = 16 * NT;                        // floats per tap of packed 
 constexpr int WCH3 = 12 * NT;                       // ... of which k-groups 0-2 (channels 0-11) are kept in LDS
 constexpr int W_FLOATS = 9 * WCH;                   // one slab, all taps, in global memory
 constexpr int W3_FLOATS = 9 * WCH3;                 // 13,824 floats = 54 KB in LDS
-constexpr size_t LDS_BYTES = (size_t)(W3_FLOATS + IN_FLOATS + NT) * sizeof(float);      // 81,728 B: two workgroups per CU
-static_assert(2 * LDS_BYTES <= 160 * 1024, "LDS budget of two workgroups per CU");
+constexpr size_t LDS_BYTES = (size_t)(W3_FLOATS + 2 * IN_FLOATS + NT) * sizeof(float);      // 107,648 B
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 }  // namespace first
 
 }  // namespace
@@ -50,15 +50,15 @@ static_assert(2 * LDS_BYTES <= 160 * 1024, "LDS budget of two workgroups per CU"
 // channel counts come in `f`.
 // ABL (diagnostic builds, timing only): 1 no stores, 2 no MFMAs, 4 no input gather.
 template <int CREAL, int COUT, int EPI, int ABL = 0>
-__global__ __launch_bounds__(first::THREADS, 4) void conv3x3_first_kernel(const ConvParams p, const FirstInputs f, const int n_items) {
+__global__ __launch_bounds__(first::THREADS, 2) void conv3x3_first_kernel(const ConvParams p, const FirstInputs f, const int n_items) {
   using namespace first;
   constexpr int NS = COUT / NT;
   constexpr int MB = 2, PB = 2;
   static_assert(CREAL % 2 == 0 && CREAL > 8 && CREAL <= 16, "first-layer form");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const w_s = smem;                                          // [9][3][128][4]
-  float* const in_s = smem + W3_FLOATS;                             // [324][PSTR]
-  float* const bias_s = in_s + IN_FLOATS;                           // [128]
+  float* const in_s = smem + W3_FLOATS;                             // [2][324][PSTR]
+  float* const bias_s = in_s + 2 * IN_FLOATS;                       // [128]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -163,16 +163,67 @@ __global__ __launch_bounds__(first::THREADS, 4) void conv3x3_first_kernel(const 
   __syncthreads();
 
   const size_t img_pix = plane;
-  for (int it = 0; it < my_items; ++it) {
+  // one 16-byte piece of a finished tile: register quad g of accumulator (mb, pb) = channels 8g + 4*hsel .. +3 of one
+  // pixel (conv3x3_mfma_kernel's epilogue); j = 8*pb + 4*mb + g
+  auto store_piece = [&](int j, const f32x16 (&h)[MB][PB], const Tile& t, bool valid) __attribute__((always_inline)) {
+    const int pb = j >> 3, mb = (j >> 2) & 1, g = j & 3;
+    const int blk = wp * PB + pb;
+    const int y = t.ty0 + 2 * blk + (l31 >> 4);
+    const int x = t.tx0 + (l31 & 15);
+    if (valid && y < p.h && x < p.w) {
+      const size_t pix = (size_t)t.img * img_pix + (size_t)y * p.w + x;
+      const int c0 = slab * NT + wn * (32 * MB) + mb * 32 + 8 * g + 4 * hsel;
+      f32x4 v = {h[mb][pb][4 * g], h[mb][pb][4 * g + 1], h[mb][pb][4 * g + 2], h[mb][pb][4 * g + 3]};
+      v += *reinterpret_cast<const f32x4*>(bias_s + c0 - slab * NT);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      if constexpr ((ABL & 1) != 0) {
+        asm volatile("" ::"v"(v));
+      } else if constexpr (EPI == kEpiRelu) {
+        *reinterpret_cast<f32x4*>(p.out + pix * COUT + c0) = v;
+      } else {
+        // blocked (hi, lo) planes [n][C/8][h][w][8] (conv3x3_body16w.hip): this lane's 4 channels are bytes
+        // 8*hsel .. 8*hsel+7 of the pixel's 16-byte piece in block c0 >> 3; lanes l and l + 32 complete it
+        unsigned h01, l01, h23, l23;
+        bf16k::split2(__float_as_uint(v[0]), __float_as_uint(v[1]), h01, l01);
+        bf16k::split2(__float_as_uint(v[2]), __float_as_uint(v[3]), h23, l23);
+        const size_t off = (((size_t)t.img * (COUT / 8) + (c0 >> 3)) * img_pix + (size_t)y * p.w + x) * 16 + (c0 & 7) * 2;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) + off) = u32x2{h01, h23};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + off) = u32x2{l01, l23};
+      }
+    }
+  };
+
+  // Rotated loop: iteration `it` first takes over tile it-1's accumulators (`held`), then computes tile `it` while
+  // held's sixteen pieces leave two per tap; one extra iteration writes the last tile out at once.
+  f32x16 acc[MB][PB], held[MB][PB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mb][pb][e] = 0.f;
+  for (int it = 0; it <= my_items; ++it) {
+    const Tile tprev = tile_of(it > 0 ? lid + (it - 1) * G : lid);
+    const bool vprev = it > 0;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) held[mb][pb] = acc[mb][pb];
+    if (it == my_items) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) store_piece(j, held, tprev, vprev);
+      break;
+    }
     const int item = lid + it * G;
-    const Tile t = tile_of(item);
-    const float* const ib = in_s;
+    const float* const ib = in_s + (it & 1) * IN_FLOATS;
+    float* const ib_next = in_s + ((it + 1) & 1) * IN_FLOATS;
     // the next tile's input: its loads fly under this tile's MFMAs (past the last item: this tile again, never read)
     float nv[ROUNDS];
     if constexpr (!(ABL & 4)) gather(tile_of(it + 1 < my_items ? item + G : item), nv);
     else for (int r = 0; r < ROUNDS; ++r) nv[r] = 1.f;
 
-    f32x16 acc[MB][PB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -181,80 +232,52 @@ __global__ __launch_bounds__(first::THREADS, 4) void conv3x3_first_kernel(const 
         for (int e = 0; e < 16; ++e) acc[mb][pb][e] = 0.f;
 
 #pragma unroll
-    for (int tap = 0; tap < ((ABL & 2) ? 0 : 9); ++tap) {
+    for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - dy * 3;
       const float* const bp = ib + b_lane + (dy * kHalo + dx) * PSTR;
       const float* const ap = w_s + tap * WCH3 + a_lane;
-      // channels 0-7: MFMA j pairs channel j (lanes 0-31) with channel 4 + j (lanes 32-63)
-      f32x4 a[MB], b[PB];
+      if constexpr (!(ABL & 2)) {
+        // channels 0-7: MFMA j pairs channel j (lanes 0-31) with channel 4 + j (lanes 32-63)
+        f32x4 a[MB], b[PB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const f32x4*>(ap + (mb * 32) * 4);
+        for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const f32x4*>(ap + (mb * 32) * 4);
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) b[pb] = *reinterpret_cast<const f32x4*>(bp + pb * 2 * kHalo * PSTR);
+        for (int pb = 0; pb < PB; ++pb) b[pb] = *reinterpret_cast<const f32x4*>(bp + pb * 2 * kHalo * PSTR);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+          for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int pb = 0; pb < PB; ++pb)
-            acc[mb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[pb][j], acc[mb][pb], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);      // (keeps hipcc from fetching several taps' fragments ahead: 128 VGPRs per wave)
-      // channels 8 .. CREAL-1: lanes 0-31 supply channel 8 + 2m, lanes 32-63 channel 9 + 2m (both from k-group 2)
+            for (int pb = 0; pb < PB; ++pb)
+              acc[mb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[pb][j], acc[mb][pb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // channels 8 .. CREAL-1: lanes 0-31 supply channel 8 + 2m, lanes 32-63 channel 9 + 2m (both from k-group 2)
 #pragma unroll
-      for (int m = 0; m < (CREAL - 8) / 2; ++m) {
-        float a1[MB], b1[PB];
+        for (int m = 0; m < (CREAL - 8) / 2; ++m) {
+          float a1[MB], b1[PB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a1[mb] = ap[(2 * NT + mb * 32) * 4 - hsel * NT * 4 + 2 * m + hsel];
+          for (int mb = 0; mb < MB; ++mb) a1[mb] = ap[(2 * NT + mb * 32) * 4 - hsel * NT * 4 + 2 * m + hsel];
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) b1[pb] = bp[pb * 2 * kHalo * PSTR + 8 - 4 * hsel + 2 * m + hsel];
+          for (int pb = 0; pb < PB; ++pb) b1[pb] = bp[pb * 2 * kHalo * PSTR + 8 - 4 * hsel + 2 * m + hsel];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+          for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int pb = 0; pb < PB; ++pb)
-            acc[mb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mb], b1[pb], acc[mb][pb], 0, 0, 0);
+            for (int pb = 0; pb < PB; ++pb)
+              acc[mb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mb], b1[pb], acc[mb][pb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      // two pieces of the previous tile, issued behind this tap's MFMAs (a version that also read the operand fragments one
+      // tap ahead and put the pieces between MFMA groups was slower: 125 vs 117 us)
+      if (tap < 8) {
+        store_piece(2 * tap, held, tprev, vprev);
+        store_piece(2 * tap + 1, held, tprev, vprev);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 
-    // ---- epilogue (conv3x3_mfma_kernel's): register quad g of accumulator (mb, pb) = channels 8g + 4*hsel .. +3 of one pixel ----
-#pragma unroll
-    for (int pb = 0; pb < PB; ++pb) {
-      const int blk = wp * PB + pb;
-      const int y = t.ty0 + 2 * blk + (l31 >> 4);
-      const int x = t.tx0 + (l31 & 15);
-      if (y < p.h && x < p.w) {
-        const size_t pix = (size_t)t.img * img_pix + (size_t)y * p.w + x;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int c0 = slab * NT + wn * (32 * MB) + mb * 32 + 8 * g + 4 * hsel;
-            f32x4 v = {acc[mb][pb][4 * g], acc[mb][pb][4 * g + 1], acc[mb][pb][4 * g + 2], acc[mb][pb][4 * g + 3]};
-            v += *reinterpret_cast<const f32x4*>(bias_s + c0 - slab * NT);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            if constexpr ((ABL & 1) != 0) {
-              asm volatile("" ::"v"(v));
-            } else if constexpr (EPI == kEpiRelu) {
-              *reinterpret_cast<f32x4*>(p.out + pix * COUT + c0) = v;
-            } else {
-              // blocked (hi, lo) planes [n][C/8][h][w][8] (conv3x3_body16w.hip): this lane's 4 channels are bytes
-              // 8*hsel .. 8*hsel+7 of the pixel's 16-byte piece in block c0 >> 3; lanes l and l + 32 complete it
-              unsigned h01, l01, h23, l23;
-              bf16k::split2(__float_as_uint(v[0]), __float_as_uint(v[1]), h01, l01);
-              bf16k::split2(__float_as_uint(v[2]), __float_as_uint(v[3]), h23, l23);
-              const size_t off = (((size_t)t.img * (COUT / 8) + (c0 >> 3)) * img_pix + (size_t)y * p.w + x) * 16 + (c0 & 7) * 2;
-              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-              *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) + off) = u32x2{h01, h23};
-              *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + off) = u32x2{l01, l23};
-            }
-          }
-        }
-      }
-    }
-    // refill the input buffer: every wave is done reading it / the next tile's halo is complete
-    __syncthreads();
-    scatter(in_s, nv);
+    // the next tile's halo into the other buffer (every wave read it for the last time one barrier ago)
+    scatter(ib_next, nv);
     __syncthreads();
   }
 }
@@ -269,7 +292,7 @@ static hipError_t launch_first_one(const ConvParams& p, const FirstInputs& f, hi
   constexpr int NS = COUT / first::NT;
   const long long items = (long long)p.n * p.tiles_x * p.tiles_y * NS;
   if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;
-  int grid = (int)(items < 2 * cus ? items : 2 * cus);      // two workgroups per CU
+  int grid = (int)(items < cus ? items : cus);
   grid -= grid % NS;                                   // a workgroup keeps one slab: item stride G must preserve item % NS
   if (grid < NS) grid = NS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(first::THREADS), first::LDS_BYTES, stream, p, f, (int)items);
