@@ -120,10 +120,13 @@ constexpr int younger_than_input(bool has_w) { return has_w ? 4 * W_PER_STEP : 0
 //     barrier — before chunk 3 stages chunk 4, and long before the last chunk stages the following item's chunk 0.  True
 //     for >= 2 patches per workgroup (a patch's items of consecutive layers are then >= 2 positions apart) and for one
 //     patch per workgroup at F = 256 (the only distance-1 pair is last item = (last tile, slab 1) -> first item, and
-//     slab 1 is input chunks 4-7).  The alternative costs 14 us per layer: the exposed drain of an epilogue.
+//     slab 1 is input chunks 4-7).  In-kernel stamps (tools/stamp_chain.py): 2.0-2.4 k cycles per boundary.
 //   * DRAINED otherwise (F = 128 with one patch per workgroup): every wave retires everything (vmcnt(0)), barrier, the
-//     next layer's first input chunk is staged and awaited.  EPI is then chosen per layer: conv-A (even) kEpiRelu hi -> t, conv-B (odd) kEpiResidual in place on
-// (hi, lo), the last one kEpiResidualF32 -> out_f32.  Same arithmetic per item as the per-layer kernels: same bits.
+//     next layer's first input chunk is staged and awaited: 6-11 k cycles per boundary.
+// EPI is chosen per layer: conv-A (even) kEpiRelu hi -> t, conv-B (odd) kEpiResidual in place on (hi, lo), the last
+// one kEpiResidualF32 -> out_f32 — three instantiations of the item loop in one kernel.  Same arithmetic per item as the
+// per-layer kernels: same bits.  Diagnostic masks of the chain kernel: 1024 drained boundaries everywhere, 2048 (timing
+// only) without the compute-only waves' wait, 4096 in-kernel stamps, 3 no epilogue traffic.
 
 template <int ABL>
 __host__ __device__ constexpr int epilogue_ops(int epi) {
