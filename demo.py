@@ -2,8 +2,10 @@
 """Counterpart of the reference's testing/demoDSen2.py (its `readh5` / `RMSE` harness, :14-35) for this repo.
 
 The reference demo needs the trained checkpoints and ground-truth tiles, all stripped from its checkout
-(.MISSING_LARGE_BLOBS); what can be demonstrated here is the same flow on the committed crop of the bundled
-T33UUB tile (tests/golden/tile_T33UUB_crop.npz, Copernicus Sentinel data, CC BY 4.0) with either
+(.MISSING_LARGE_BLOBS); what can be demonstrated here is the same flow on the tiles the reference DOES ship
+(Copernicus Sentinel data, CC BY 4.0, committed as uint16 under tests/golden/): --tile crop (default: a 264x264 crop of
+T33UUB, seconds), --tile T33UUB or --tile T49JGM (the whole 600x600 tiles, as testing/demoDSen2.py:42-43,67-68 reads
+them from data/*.mat; about a minute of float64 oracle), or --tile FILE (.npz / .mat, via dsen2_amd.cli._load), with either
   * --models DIR : real checkpoints (keras .hdf5 with h5py, or converted .npy) -> super-resolved bands, or
   * default      : seeded random-init weights, compared against the float64 oracle pipeline so the printed
                    RMSE is a parity figure, printed in the reference's format ("RMSE: %.4f").
@@ -33,12 +35,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--models', default=None, help='directory with s2_032/s2_030 checkpoints (.hdf5 or .npy)')
     ap.add_argument('--no-oracle', action='store_true')
+    ap.add_argument('--tile', default='crop', help='crop | T33UUB | T49JGM | a .npz / .mat file')
     args = ap.parse_args()
 
-    from dsen2_amd import supres, weights
-    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'tile_T33UUB_crop.npz'))
-    d10, d20, d60 = (g[k].astype(np.float32) for k in ('d10', 'd20', 'd60'))
-    print('tile crop: im10 %s im20 %s im60 %s' % (d10.shape, d20.shape, d60.shape))
+    from dsen2_amd import cli, supres, weights
+    committed = {'crop': 'tile_T33UUB_crop.npz', 'T33UUB': 'tile_T33UUB_600.npz', 'T49JGM': 'tile_T49JGM_600.npz'}
+    if args.tile in committed:
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', committed[args.tile]))
+        d10, d20, d60 = (g[k].astype(np.float32) for k in ('d10', 'd20', 'd60'))
+    else:
+        d10, d20, d60 = (np.asarray(a, np.float32) for a in cli._load(args.tile))        # readh5, testing/demoDSen2.py:14-28
+    print('tile %s: im10 %s im20 %s im60 %s' % (args.tile, d10.shape, d20.shape, d60.shape))
 
     tmp = None
     if args.models:
