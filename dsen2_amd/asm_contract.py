@@ -18,6 +18,12 @@ the two translation units to ISA with exactly the product's flags and fails (Asm
     as younger than their target (conv3x3_body16w.hip, E_OPS): an over-count there would be a weaker wait;
   * nothing is called out of line (an epilogue that is not inlined passes 128 accumulators through memory).
 
+The matrix-core output convolution (conv3x3_out_mfma.hip) has no inline-asm DMA, but its speed rests on where hipcc
+puts the waits for its operand loads (one unit = 8 loads ahead, issued in two halves): `check_out_mfma_listing` fails unless
+no instantiation spills and every vector-memory wait between a kernel's first and last MFMA is `vmcnt(8)` or weaker (group J
+of a unit has 11 - J or 15 - J younger loads) — a smaller count means the MFMAs wait for loads issued just before them
+(what a conditional fetch produced).
+
 dsen2_amd.build runs it on every product build; tests/test_dma_asm_contract.py runs it in the CPU suite.
 """
 import os
@@ -142,14 +148,36 @@ def check_listing(text, src):
         need(chains == 2, 'expected the 2 product instantiations of the chain kernel, found %d' % chains)
 
 
+def check_out_mfma_listing(text, src='conv3x3_out_mfma.hip'):
+    def need(cond, msg, ctx=()):
+        if not cond:
+            raise AsmContractError('%s: %s %s' % (src, msg, list(ctx)))
+
+    kernels = {k: v for k, v in _kernels(text).items() if 'conv3x3_out_mfma_kernel' in k}
+    need(len(kernels) == 4, 'expected 4 instantiations of the output kernel, found %d' % len(kernels))
+    for name, body in kernels.items():
+        need(not any('scratch_' in ln for ln in body), 'kernel %s spills registers' % name)
+        need(not any(ln.startswith(('s_swappc', 's_call')) for ln in body), 'kernel %s calls a function' % name)
+        mf = [i for i, ln in enumerate(body) if ln.startswith('v_mfma')]
+        need(mf, 'kernel %s has no MFMA' % name)
+        waits = [ln for ln in body[mf[0]:mf[-1]] if ln.startswith('s_waitcnt') and 'vmcnt' in ln]
+        need(len(waits) >= 8, 'kernel %s: no operand waits between its MFMAs' % name)
+        bad = [ln for ln in waits if int(re.search(r'vmcnt\((\d+)\)', ln).group(1)) < 8]
+        need(not bad, 'kernel %s waits for the loads of the NEXT unit' % name, bad[:4])
+    return True
+
+
 def check_sources(hipcc, flags, verbose=False):
     with tempfile.TemporaryDirectory(prefix='dsen2_asm_') as tmp:
-        for src in DMA_SOURCES:
+        for src in DMA_SOURCES + ['conv3x3_out_mfma.hip']:
             out = os.path.join(tmp, src + '.s')
             cmd = [hipcc] + [f for f in flags if f not in ('-fPIC',)] + ['-S', '--cuda-device-only', os.path.join(CSRC, src), '-o', out]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
             with open(out) as f:
-                check_listing(f.read(), src)
+                if src in DMA_SOURCES:
+                    check_listing(f.read(), src)
+                else:
+                    check_out_mfma_listing(f.read(), src)
     return True

@@ -100,7 +100,7 @@ int dsen2_diag_set(int key, int value) {
     return DSEN2_OK;
   }
   if (key == 2) {
-    if (value != 0 && value != 2) return fail(DSEN2_ERR_INVALID, "output variant %d unknown", value);
+    if (value != 0 && value != 2 && value != 3) return fail(DSEN2_ERR_INVALID, "output variant %d unknown", value);
     g_diag_tuning.out_variant = value;
     return DSEN2_OK;
   }
@@ -110,6 +110,10 @@ int dsen2_diag_set(int key, int value) {
   }
   if (key == 5) {   // timing-only ablation mask of the first convolution (1 no stores, 2 no MFMAs, 4 no gather)
     g_diag_tuning.first_ablate = value;
+    return DSEN2_OK;
+  }
+  if (key == 6) {   // timing-only ablation mask of the matrix-core output convolution (conv3x3_out_mfma.hip)
+    g_diag_tuning.out_ablate = value;
     return DSEN2_OK;
   }
   if (key == 4) {   // 0 = always launch the bf16 body convolutions layer by layer (A/B against the chain kernel)
@@ -363,7 +367,11 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
   if (ev_body1) HIP_TRY(hipEventRecord(ev_body1, stream));
   {
     const Layer& L = m->layers[li++];            // DSen2Net.py:35,38,41
-    HIP_TRY(launch_conv3x3(make_params(a, P + L.w_off, P + L.b_off, skip, out, n, h, w, m->cout, 0.f), L.geom, L.epilogue, 0, stream));
+    ConvParams po = make_params(a, P + L.w_off, P + L.b_off, skip, out, n, h, w, m->cout, 0.f);
+#ifdef DSEN2_DIAG
+    po.diag = g_diag_stamps;
+#endif
+    HIP_TRY(launch_conv3x3(po, L.geom, L.epilogue, m->tune.out_ablate, stream));
   }
   return DSEN2_OK;
 }

@@ -302,7 +302,12 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, const Tuning& tune, Pac
   if (cin <= 0 || cout <= 0) return false;
   if (epilogue == kEpiSkipNCHW) {
     if (cout > 32 || (cin != 128 && cin != 256)) return false;
-    if (cout <= 8 && tune.out_variant == 2) { *g = PackGeom{16, 8, cin, 8, 8}; return true; }      // conv3x3_out.hip, vector units
+    // variant 8: conv3x3_out_mfma.hip where the shape fits, else conv3x3_out.hip (the buffer holds both packings);
+    // variant 9: conv3x3_out.hip always
+    if (cout <= 8 && (tune.out_variant == 2 || tune.out_variant == 3)) {
+      *g = PackGeom{16, 8, cin, 8, tune.out_variant == 2 ? 8 : 9};
+      return true;
+    }
     *g = PackGeom{32, 32, cin, 32, 0};
     return true;
   }
@@ -322,11 +327,14 @@ bool conv_pack_geometry(int cin, int cout, int epilogue, const Tuning& tune, Pac
   return false;
 }
 
-size_t packed_weight_floats(const PackGeom& g) { return (size_t)9 * g.cin_pad * g.cout_pad; }
+size_t packed_weight_floats(const PackGeom& g) {
+  return (size_t)9 * g.cin_pad * g.cout_pad + (g.variant == 8 ? out_mfma_weight_floats(g.cin_pad) : 0);
+}
 
 void pack_conv_weights_host(const float* k, int cin, int cout, const PackGeom& g, float* dst) {
-  if (g.variant == 8) {          // the vector-unit output kernel has its own operand order
+  if (g.variant == 8 || g.variant == 9) {          // the output kernels have their own operand orders
     pack_out_valu_weights_host(k, cin, cout, dst);
+    if (g.variant == 8) pack_out_mfma_weights_host(k, cin, cout, dst + (size_t)9 * cin * 8);
     return;
   }
   const int ncc = g.cin_pad / g.kc, nslab = g.cout_pad / g.nt, ng = g.kc / 4;
@@ -372,7 +380,16 @@ void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch
 
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, int ablate, hipStream_t stream) {
   const int cin_pad = geom.cin_pad, cout_pad = geom.cout_pad;
-  if (geom.variant == 8 && epilogue == kEpiSkipNCHW) return launch_conv3x3_out_valu(p, cin_pad, stream);
+  if ((geom.variant == 8 || geom.variant == 9) && epilogue == kEpiSkipNCHW) {
+    if (geom.variant == 8) {
+      ConvParams pm = p;
+      pm.wpk = p.wpk + (size_t)9 * cin_pad * 8;
+      bool taken = false;
+      const hipError_t e = launch_conv3x3_out_mfma(pm, cin_pad, stream, &taken, ablate);
+      if (e != hipSuccess || taken) return e;
+    }
+    return launch_conv3x3_out_valu(p, cin_pad, stream);
+  }
   // 11-14: the DMA-fed kernel (conv3x3_body32.hip) and its sub-variants.  An image it cannot address (>= 2 GiB of
   // activations) is an error, not a silent switch of kernels: dsen2's entry points reject such shapes up front.
   if (geom.variant >= 11 && geom.variant <= 14 && cin_pad == cout_pad && epilogue != kEpiSkipNCHW)

@@ -52,11 +52,13 @@ struct ConvParams {
 struct Tuning {
   int body_variant = 14;   // fp32 F->F body convolution: 11-14 = conv3x3_body32.hip sub-variants 0-3; 0 = one tile per
                            // workgroup (conv3x3_mfma.hip, the independent first implementation)
-  int out_variant = 2;     // last layer: 2 = vector-unit kernel for Cout <= 8 (conv3x3_out.hip; falls back to 0 above 8),
-                           // 0 = padded 32-wide MFMA block (conv3x3_mfma.hip, the reference structure)
+  int out_variant = 2;     // last layer, Cout <= 8: 2 = the tap-expanded matrix-core kernel (conv3x3_out_mfma.hip) where the
+                           // shape fits it, else the vector-unit kernel (conv3x3_out.hip); 3 = always the vector-unit kernel;
+                           // 0 (and Cout > 8) = padded 32-wide MFMA block (conv3x3_mfma.hip, the reference structure)
   int ablate = 0;          // timing-only ablation mask of the persistent body kernels (DSEN2_DIAG builds; wrong outputs)
   int grid_cap = 0;        // DSEN2_DIAG builds: launch at most this many workgroups of the bf16 body kernel (0 = one per CU)
   int first_ablate = 0;    // DSEN2_DIAG builds: timing-only ablation mask of the first convolution (conv3x3_first.hip)
+  int out_ablate = 0;      // DSEN2_DIAG builds: timing-only ablation mask of conv3x3_out_mfma.hip
   int chain = 1;           // precision 1: one persistent launch over all body layers when the batch gives every CU whole patches
 };
 
@@ -95,6 +97,12 @@ hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogu
 // pack_out_valu_weights_host)
 hipError_t launch_conv3x3_out_valu(const ConvParams& p, int feat, hipStream_t stream);
 void pack_out_valu_weights_host(const float* kernel_hwio, int cin, int cout, float* dst);
+// last layer, F -> Cout <= 6, the nine taps expanded into the M side of one GEMM (conv3x3_out_mfma.hip).  Its weights follow
+// the vector-unit kernel's in a variant-8 buffer (9 * cin * 8 floats further).  *taken = false: shape not supported,
+// nothing launched.
+hipError_t launch_conv3x3_out_mfma(const ConvParams& p, int feat, hipStream_t stream, bool* taken, int ablate = 0);
+size_t out_mfma_weight_floats(int cin);
+void pack_out_mfma_weights_host(const float* kernel_hwio, int cin, int cout, float* dst);
 // First convolution reading the NCHW inputs directly (conv3x3_first.hip): p.in = x10, p.aux = x20; weights packed with
 // PackGeom{16, 128, 16, cout, .}; epilogue kEpiRelu (p.out fp32 NHWC) or kEpiReluSplit (p.out / p.out2 = (hi, lo) planes).
 // hipErrorNotSupported for channel counts other than 10 / 12 (then: launch_pack_inputs + launch_conv3x3).

@@ -86,6 +86,62 @@ def test_conv_out_skip_nchw_matches_oracle(feat, cout, n, h, w):
     assert do.rmse(y, ref) < _tol(feat)
 
 
+# shapes of the tap-expanded matrix-core output kernel (conv3x3_out_mfma.hip): rows cut into 32-pixel blocks (edges at
+# x = 31 | 32), several rows per wave and phase (W <= 64), strips of rows when there are few images, Cout 6 and 2, F = 256;
+# and shapes it hands to the vector-unit kernel (Cout 7, a row of Q too wide for LDS)
+OUT_SHAPES = [(128, 6, 1, 128, 128), (128, 2, 1, 50, 192), (128, 6, 3, 40, 70), (256, 6, 1, 33, 64), (128, 5, 2, 7, 31),
+              (128, 3, 1, 1, 1), (256, 2, 2, 67, 33), (128, 6, 1, 70, 97), (128, 7, 1, 20, 40), (128, 6, 1, 9, 230)]
+
+
+@pytest.mark.parametrize('feat,cout,n,h,w', OUT_SHAPES)
+def test_conv_out_shapes_match_oracle(feat, cout, n, h, w):
+    rng = np.random.default_rng(feat + cout + h)
+    x = _rand(rng, (n, feat, h, w))
+    skip = _rand(rng, (n, cout, h, w))
+    k = _rand(rng, (3, 3, feat, cout), np.sqrt(2.0 / (9 * feat)))
+    b = _rand(rng, (cout,), 0.1)
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    y = conv3x3_nhwc(_nhwc(x), k, b, epilogue=2, aux=torch.from_numpy(skip).cuda()).cpu().numpy()
+    ref = c_oracle.conv3x3(x, k, b) + skip
+    assert y.shape == (n, cout, h, w)
+    assert do.rmse(y, ref) < _tol(feat)
+    assert np.abs(y - ref).max() < 40 * _tol(feat)          # no single pixel off (a block edge, a strip's first row)
+
+
+@pytest.mark.parametrize('feat,cout,h,w', [(128, 6, 32, 32), (128, 6, 45, 100), (128, 2, 40, 192), (256, 6, 20, 64)])
+def test_conv_out_delta_kernels_shift_exactly(feat, cout, h, w):
+    """Known-answer for the output convolution: a one-hot kernel copies a shifted input channel bit-exactly into ONE
+    output channel (zero outside the image, across every block edge and strip boundary), bias and skip added after."""
+    rng = np.random.default_rng(h + w)
+    x = _rand(rng, (1, feat, h, w))
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    zero = torch.zeros(1, cout, h, w, device='cuda')
+    for dy, dx, ci, co in [(0, 0, 3, cout - 1), (2, 1, feat - 1, 0), (1, 1, feat // 2, 1), (0, 2, 31, 0), (2, 2, 64, cout - 1),
+                           (1, 0, 95, 1), (2, 0, 7, 0)]:
+        k = np.zeros((3, 3, feat, cout), np.float32); k[dy, dx, ci, co] = 1
+        y = conv3x3_nhwc(_nhwc(x), k, np.zeros(cout, np.float32), epilogue=2, aux=zero).cpu().numpy()
+        exp = np.zeros((h, w), np.float32)
+        ys = slice(max(0, 1 - dy), min(h, h + 1 - dy)); xs = slice(max(0, 1 - dx), min(w, w + 1 - dx))
+        exp[ys, xs] = x[0, ci, ys.start + dy - 1:ys.stop + dy - 1, xs.start + dx - 1:xs.stop + dx - 1]
+        assert np.array_equal(y[0, co], exp), (dy, dx, ci, co)
+        assert not np.delete(y[0], co, axis=0).any()
+
+
+def test_conv_out_does_not_depend_on_how_the_image_is_cut():
+    """The same image alone (cut into strips of rows, one per workgroup) and inside a batch of 600 (a workgroup takes the
+    whole image): the same bits — every sum's order is fixed by (y, x)."""
+    rng = np.random.default_rng(77)
+    x = _rand(rng, (1, 128, 64, 64)); skip = _rand(rng, (1, 6, 64, 64))
+    k = _rand(rng, (3, 3, 128, 6), np.sqrt(2.0 / (9 * 128))); b = _rand(rng, (6,), 0.1)
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    alone = conv3x3_nhwc(_nhwc(x), k, b, epilogue=2, aux=torch.from_numpy(skip).cuda())
+    xb = torch.zeros(600, 64, 64, 128, device='cuda'); xb[417] = _nhwc(x)[0]
+    sb = torch.zeros(600, 6, 64, 64, device='cuda'); sb[417] = torch.from_numpy(skip[0]).cuda()
+    batch = conv3x3_nhwc(xb, k, b, epilogue=2, aux=sb)
+    assert torch.equal(batch[417], alone[0])
+    assert torch.equal(batch[0], torch.from_numpy(np.broadcast_to(b[:, None, None], (6, 64, 64)).copy()).cuda())
+
+
 def test_delta_kernel_shifts_exactly():
     """Known-answer: a one-hot kernel copies a shifted input channel bit-exactly (zero outside)."""
     rng = np.random.default_rng(9)
