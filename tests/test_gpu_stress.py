@@ -61,3 +61,43 @@ def test_chain_kernel_over_many_launches_on_fresh_data(feat, d, n):
             sub = m.forward_device([t[first:first + 5].contiguous() for t in xs])
             bad += int((sub != y[first:first + 5]).sum())
     assert bad == 0
+
+
+def test_output_conv_fuzz_against_the_oracle_and_the_reference_structure():
+    """conv3x3_out_mfma.hip over random shapes (one or several 32-pixel blocks per row, 1-4 rows per wave, strips of rows, Cout
+    1..6, F 128 / 256): every element against the float64 oracle; then many launches on fresh data at bench-like sizes against
+    the independent one-tile-per-workgroup kernel (dsen2_conv3x3_nhwc_ref), and run-to-run bit identity."""
+    import numpy as np
+    from dsen2_amd.DSen2Net import conv3x3_nhwc
+    from oracle import c_oracle
+    rng = np.random.default_rng(2024)
+    for it in range(24):
+        feat = (128, 256)[it % 2]
+        cout = int(rng.integers(1, 7))
+        n, h, w = int(rng.integers(1, 5)), int(rng.integers(1, 75)), int(rng.integers(1, 140))
+        x = rng.standard_normal((n, feat, h, w)).astype(np.float32)
+        skip = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+        k = (rng.standard_normal((3, 3, feat, cout)) * np.sqrt(2.0 / (9 * feat))).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        xd = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).cuda()
+        y = conv3x3_nhwc(xd, k, b, epilogue=2, aux=torch.from_numpy(skip).cuda()).cpu().numpy()
+        ref = c_oracle.conv3x3(x, k, b) + skip
+        assert np.abs(y - ref).max() < 2e-5, (feat, cout, n, h, w, float(np.abs(y - ref).max()))
+    g = torch.Generator(device='cuda'); g.manual_seed(7)
+    worst = 0.0
+    for it in range(30):
+        feat, cout = ((128, 6), (128, 2), (256, 6))[it % 3]
+        n, h, w = ((512, 32, 32), (40, 128, 128), (300, 32, 32), (7, 192, 192), (64, 64, 48))[it % 5]
+        if feat == 256:
+            n = max(1, n // 2)
+        xd = torch.randn((n, h, w, feat), device='cuda', generator=g)
+        sd = torch.randn((n, cout, h, w), device='cuda', generator=g)
+        k = (rng.standard_normal((3, 3, feat, cout)) * np.sqrt(2.0 / (9 * feat))).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        a = conv3x3_nhwc(xd, k, b, epilogue=2, aux=sd)
+        a2 = conv3x3_nhwc(xd, k, b, epilogue=2, aux=sd)
+        r = conv3x3_nhwc(xd, k, b, epilogue=2, aux=sd, ref=True)
+        assert torch.equal(a, a2), (it, 'not deterministic')
+        worst = max(worst, float((a - r).abs().max()))
+        assert worst < 4e-5, (it, feat, cout, n, h, w, worst)
+        del xd, sd, a, a2, r
