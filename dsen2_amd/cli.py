@@ -123,6 +123,43 @@ def tidy_description(description, fmt):
     return description
 
 
+class LazyRows(object):
+    """An HWC image whose rows are read when asked for: `img[r0:r1]` reads (decodes) those rows only.  Under
+    torch.distributed every rank runs this command line, and DSen2_20 / DSen2_60 slice exactly the rows their share of the
+    patches needs (supres._run: `d[r0:r1]`) — with a lazily read product a rank decodes 1/world of the JPEG2000 tile
+    instead of all of it.  The last window is kept, with a margin, so that the second network's slightly different
+    window (patches of 128 vs 192) is served from memory; `np.asarray(img)` reads everything."""
+    MARGIN_10M = 192          # rows of the 10 m image kept either side of a requested window
+
+    def __init__(self, read_rows, shape, dtype, margin=0):
+        self._read, self.shape, self.dtype, self._margin = read_rows, tuple(int(v) for v in shape), np.dtype(dtype), int(margin)
+        self.ndim = 3
+        self._win = None          # (r0, r1, array)
+        self.rows_read = 0        # rows decoded so far (tests, and the line the command prints per rank)
+
+    def _window(self, r0, r1):
+        if self._win is None or r0 < self._win[0] or r1 > self._win[1]:
+            a0, a1 = max(0, r0 - self._margin), min(self.shape[0], r1 + self._margin)
+            self._win = (a0, a1, self._read(a0, a1))
+            self.rows_read += a1 - a0
+        return self._win[2][r0 - self._win[0]:r1 - self._win[0]]
+
+    def __getitem__(self, key):
+        rows = key[0] if isinstance(key, tuple) else key
+        if isinstance(rows, slice) and rows.step in (None, 1):
+            r0, r1, _ = rows.indices(self.shape[0])
+            part = self._window(r0, max(r0, r1))
+            return part[(slice(None),) + tuple(key[1:])] if isinstance(key, tuple) else part
+        return np.asarray(self)[key]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._window(0, self.shape[0])
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self):
+        return self.shape[0]
+
+
 class GdalProduct(object):
     """The GDAL side of s2_tiles_supres.py for one product: which sub-datasets and bands, the ROI, the arrays."""
 
@@ -198,18 +235,29 @@ class GdalProduct(object):
                       for b in range(ds.RasterCount if ds is not None else 0)]
         return lines + ['']
 
-    def read(self, key):
-        """HWC array of the selected bands of one resolution, ROI applied (:311-329)."""
+    def read(self, key, row0=0, row1=None):
+        """HWC array of the selected bands of one resolution, ROI applied (:311-329); rows [row0, row1) of it only when
+        given (rows of THAT resolution, counted from the ROI's first row)."""
         if not self.index[key]:
             return None
         div = {'10m': 1, '20m': 2, '60m': 6}[key]
         xs, ys = (self.xmax - self.xmin + 1) // div, (self.ymax - self.ymin + 1) // div
-        a = self.ds[key].ReadAsArray(xoff=self.xmin // div, yoff=self.ymin // div, xsize=xs, ysize=ys,
-                                     buf_xsize=xs, buf_ysize=ys)
+        row1 = ys if row1 is None else row1
+        a = self.ds[key].ReadAsArray(xoff=self.xmin // div, yoff=self.ymin // div + row0, xsize=xs, ysize=row1 - row0,
+                                     buf_xsize=xs, buf_ysize=row1 - row0)
         a = np.asarray(a)
         if a.ndim == 2:
             a = a[None]
         return np.moveaxis(a, 0, 2)[:, :, self.index[key]]
+
+    def rows(self, key):
+        """The same image as `read(key)`, read on demand: see LazyRows."""
+        if not self.index[key]:
+            return None
+        div = {'10m': 1, '20m': 2, '60m': 6}[key]
+        probe = self.read(key, 0, 1)
+        shape = ((self.ymax - self.ymin + 1) // div, (self.xmax - self.xmin + 1) // div, len(self.index[key]))
+        return LazyRows(lambda r0, r1: self.read(key, r0, r1), shape, probe.dtype, margin=LazyRows.MARGIN_10M // div)
 
     def writer(self, path, width, height, nbands):
         """A GDAL dataset to write `nbands` float64 bands into, geo-referenced to the ROI (:371-382); None when the
@@ -364,7 +412,12 @@ def _run(args):
             print('Selected %s bands: %s' % (key, ' '.join(product.names[key])))
         if args.list_bands:
             return 0
-        data10, data20, data60 = product.read('10m'), product.read('20m'), product.read('60m')
+        from . import dist as _dist
+        if _dist.rank_world()[1] > 1:
+            # one process per GPU: each reads the rows its patches need, when DSen2_20 / DSen2_60 ask for them
+            data10, data20, data60 = product.rows('10m'), product.rows('20m'), product.rows('60m')
+        else:
+            data10, data20, data60 = product.read('10m'), product.read('20m'), product.read('60m')
         names10, names20, names60 = product.names['10m'], product.names['20m'], product.names['60m']
         descriptions = product.descriptions
         if data10 is None or data20 is None:
@@ -384,8 +437,12 @@ def _run(args):
         sr60 = supres.DSen2_60(data10, data20, data60, deep=args.deep)
     print('Super-resolving the 20m data into 10m bands')
     sr20 = supres.DSen2_20(data10, data20, deep=args.deep)
+    if isinstance(data10, LazyRows):
+        sys.stderr.write('rank %d read %d of %d rows of the 10 m bands\n' % (_dist.rank_world()[0], data10.rows_read, data10.shape[0]))
     if sr20 is None:                                               # a rank other than 0 of a multi-GPU run
         return 0
+    if args.copy_original_bands:
+        data10 = np.asarray(data10)                                # rank 0 writes them: all rows after all
 
     if sr60 is not None:
         sr, sr_names = np.concatenate((sr20, sr60), axis=2), names20 + names60

@@ -279,3 +279,47 @@ def test_array_input_validates_the_roi_and_says_what_it_ignores(fake_supres, tmp
     assert 'need a geo-referenced product' in capsys.readouterr().out
     with pytest.raises(SystemExit):
         cli.main([])
+
+
+def test_lazy_rows_read_what_is_asked_for_once():
+    """cli.LazyRows: a row window is read when asked for, kept with its margin, re-read only when a request leaves it."""
+    from dsen2_amd.cli import LazyRows
+    full = np.arange(100 * 7 * 3, dtype=np.uint16).reshape(100, 7, 3)
+    calls = []
+
+    def read(r0, r1):
+        calls.append((r0, r1))
+        return full[r0:r1]
+    z = LazyRows(read, full.shape, full.dtype, margin=5)
+    assert z.shape == (100, 7, 3) and z.dtype == np.uint16 and len(z) == 100 and z.rows_read == 0
+    assert np.array_equal(z[20:40], full[20:40]) and calls == [(15, 45)] and z.rows_read == 30
+    assert np.array_equal(z[17:44], full[17:44]) and len(calls) == 1                    # inside the kept window
+    assert np.array_equal(z[22:30, :4], full[22:30, :4]) and len(calls) == 1            # tuple keys: rows first
+    assert np.array_equal(z[90:100], full[90:100]) and calls[-1] == (85, 100)           # clipped at the image's end
+    assert z[50:50].shape == (0, 7, 3)
+    assert np.array_equal(np.asarray(z), full) and calls[-1] == (0, 100)
+    assert np.array_equal(z[:, :, 1], full[:, :, 1])
+
+
+def test_gdal_branch_reads_rows_on_demand_under_torch_distributed(with_gdal, tmp_path, capsys, monkeypatch):
+    """Several ranks: the command line hands DSen2_20 / DSen2_60 lazily read images, so a rank decodes only the rows its
+    patches need (here: a stand-in that, like supres._run, slices the rows of the upper half)."""
+    from dsen2_amd import cli, dist, supres
+    d10, d20, d60 = _arrays(96)
+    with_gdal(d10, d20, d60)
+    seen = {}
+
+    def fake20(a10, a20, deep=False):
+        seen['types'] = (type(a10).__name__, type(a20).__name__)
+        part10, part20 = a10[0:56], a20[0:28]                     # what a rank holding the upper patches uploads
+        seen['rows'] = (a10.rows_read, a20.rows_read)
+        assert part10.shape == (56, 96, 4) and part20.shape == (28, 48, 6)
+        assert np.array_equal(part10, np.asarray(a10)[0:56]) and np.array_equal(part20, np.asarray(a20)[0:28])
+        assert sorted(np.asarray(a10)[5, 7].tolist()) == sorted(d10[5, 7].tolist())
+        return np.repeat(np.repeat(np.asarray(a20, np.float32), 2, axis=0), 2, axis=1)
+    monkeypatch.setattr(supres, 'DSen2_20', fake20)
+    monkeypatch.setattr(dist, 'rank_world', lambda: (0, 2))
+    monkeypatch.setattr(cli.LazyRows, 'MARGIN_10M', 0)
+    assert cli.main(['S2A.zip', str(tmp_path / 'o.tif'), '--copy_original_bands']) == 0
+    assert seen['types'] == ('LazyRows', 'LazyRows') and seen['rows'] == (56, 28)
+    assert 'rank 0 read' in capsys.readouterr().err

@@ -57,6 +57,19 @@ def test_full_tile_two_ranks_gloo_matches_single_rank():
     assert r['n_gpus'] == 2 and r['patches20'] == 36 and r['matches_single_rank'] is True
 
 
+def test_full_tile_two_ranks_read_only_their_rows():
+    """Images handed over as cli.LazyRows (what the GDAL branch of the command line does under torch.distributed): each of
+    two ranks reads the rows its patches need — about half the tile, not all of it — and the result is the single-rank image."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', _free_port(), os.path.join(ROOT, 'tools', 'bench_full_tile.py'), '--size', '1200',
+           '--backend', 'gloo', '--check', '--lazy', '192']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert r['n_gpus'] == 2 and r['matches_single_rank'] is True
+    assert 0.45 < r['largest_share_of_rows_read_by_a_rank'] < 0.85, r        # half the tile + the margin kept for DSen2_60's window
+
+
 def test_full_tile_three_ranks_gloo_uneven_shards():
     """3 ranks over 36 patches of a non-dividing tile size (uneven shards, ragged last tile row/column)."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr',

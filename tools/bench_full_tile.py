@@ -31,6 +31,7 @@ ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'])
 ap.add_argument('--check', action='store_true', help='multi-rank: also verify the result against a single-rank run')
 ap.add_argument('--precision', default=None, choices=['fp32', 'bf16'], help="supres.PRECISION (default: DSEN2_PRECISION or fp32)")
 ap.add_argument('--deep', action='store_true', help='VDSen2 (d=32, F=256) instead of DSen2')
+ap.add_argument('--lazy', type=int, default=-1, metavar='MARGIN', help='hand the images over as cli.LazyRows (rows read on demand, as the GDAL branch of the command line does under torch.distributed) with this margin of 10 m rows; reports the largest share of rows a rank read')
 ap.add_argument('--port', type=int, default=0, help=argparse.SUPPRESS)
 args = ap.parse_args()
 
@@ -45,6 +46,16 @@ rng = np.random.default_rng(0)
 d10 = rng.integers(35, 13110, size=(n, n, 4), dtype=np.uint16)
 d20 = rng.integers(35, 13110, size=(n // 2, n // 2, 6), dtype=np.uint16)
 d60 = rng.integers(35, 13110, size=(n // 6, n // 6, 2), dtype=np.uint16)
+a10, a20, a60 = d10, d20, d60         # the arrays themselves: warm-up crops
+lazy = []
+if args.lazy >= 0:
+    from dsen2_amd.cli import LazyRows
+
+    def _lazy(a, div):
+        z = LazyRows(lambda r0, r1, a=a: a[r0:r1], a.shape, a.dtype, margin=args.lazy // div)
+        lazy.append(z)
+        return z
+    d10, d20, d60 = _lazy(d10, 1), _lazy(d20, 2), _lazy(d60, 6)
 tmp = tempfile.mkdtemp()
 if args.deep:                       # testing/supres.py:55-57: VDSen2 reads s2_033 / s2_034
     np.save(os.path.join(tmp, 's2_033_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 32, 256, seed=13))
@@ -66,7 +77,7 @@ def timed(fn, *a):
 
 
 with contextlib.redirect_stdout(io.StringIO()):
-    supres.DSen2_20(d10[:240, :240], d20[:120, :120], args.deep)       # warm-up: library load, model build, weight upload
+    supres.DSen2_20(a10[:240, :240], a20[:120, :120], args.deep)       # warm-up: library load, model build, weight upload
 y20, t20 = timed(supres.DSen2_20, d10, d20, args.deep)
 if world > 1:                       # whole-job wall time: the slowest rank's
     tt = torch.tensor([t20], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
@@ -81,7 +92,7 @@ else:
     assert y20 is None              # only rank 0 receives, recomposes and downloads
 if not args.skip60:
     with contextlib.redirect_stdout(io.StringIO()):
-        supres.DSen2_60(d10[:384, :384], d20[:192, :192], d60[:64, :64], args.deep)
+        supres.DSen2_60(a10[:384, :384], a20[:192, :192], a60[:64, :64], args.deep)
     y60, t60 = timed(supres.DSen2_60, d10, d20, d60, args.deep)
     if world > 1:
         tt = torch.tensor([t60], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
@@ -91,6 +102,13 @@ if not args.skip60:
     out['dsen2_60_equiv_32x32_patches_per_s'] = round(out['patches60'] * 36 / t60, 1)
     assert (y60.shape == (n, n, 2)) if rank == 0 else (y60 is None)
 out['peak_gpu_mem_gib'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+if lazy:
+    share = max(z.rows_read / float(z.shape[0]) for z in lazy)      # both networks' windows (the second mostly from the kept one)
+    if world > 1:
+        tt = torch.tensor([share], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        share = float(tt.item())
+    out['largest_share_of_rows_read_by_a_rank'] = round(share, 3)
 if world > 1 and args.check:
     td.barrier()
     td.destroy_process_group()            # dist.rank_world() now reports (0, 1): every rank computes everything
