@@ -45,6 +45,8 @@ SIGNATURES = {
                                            c_void_p, c_float_p]),
     'dsen2_upsample_mirror_bilinear': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float,
                                                c_void_p]),
+    'dsen2_upsample_mirror_bilinear_ref': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float,
+                                                   c_void_p]),
     'dsen2_tile_gather': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float,
                                   c_void_p, c_void_p]),
     'dsen2_recompose': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float,

@@ -557,15 +557,25 @@ int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, c
   return DSEN2_OK;
 }
 
-int dsen2_upsample_mirror_bilinear(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow,
-                                   float post_divisor, void* stream) {
+static int upsample_impl(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow, float post_divisor,
+                         void* stream, bool general) {
   if (!dev_in || !dev_out || planes < 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || post_divisor == 0.f)
     return fail(DSEN2_ERR_INVALID, "bad argument");
   if ((size_t)h * w >= ((size_t)1 << 31) || (size_t)oh * ow >= ((size_t)1 << 31))
     return fail(DSEN2_ERR_INVALID, "plane too large");
   if (planes == 0) return DSEN2_OK;
-  HIP_TRY(launch_upsample(dev_in, dev_out, planes, h, w, oh, ow, post_divisor, (hipStream_t)stream));
+  HIP_TRY(launch_upsample(dev_in, dev_out, planes, h, w, oh, ow, post_divisor, (hipStream_t)stream, general));
   return DSEN2_OK;
+}
+
+int dsen2_upsample_mirror_bilinear(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow,
+                                   float post_divisor, void* stream) {
+  return upsample_impl(dev_in, dev_out, planes, h, w, oh, ow, post_divisor, stream, false);
+}
+
+int dsen2_upsample_mirror_bilinear_ref(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow,
+                                       float post_divisor, void* stream) {
+  return upsample_impl(dev_in, dev_out, planes, h, w, oh, ow, post_divisor, stream, true);
 }
 
 int dsen2_tile_gather(const float* dev_img, int H, int W, int C, int border, const int* dev_origins, int count, int P,

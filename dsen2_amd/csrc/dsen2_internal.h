@@ -153,8 +153,9 @@ void pack_conv_weights_host(const float* kernel_hwio, int cin, int cout, const P
 // concat(x10,x20,x60) NCHW -> NHWC with 16 channels (zero padded): folds keras Concatenate(axis=1).
 hipError_t launch_pack_inputs(const float* x10, const float* x20, const float* x60, int c10, int c20, int c60,
                               float* out_nhwc16, int n, int h, int w, hipStream_t stream);
+// general = true: always the general kernel (the windowed one otherwise takes up-sampling by 2 or more)
 hipError_t launch_upsample(const float* in, float* out, int planes, int h, int w, int oh, int ow, float post_div,
-                           hipStream_t stream);
+                           hipStream_t stream, bool general = false);
 hipError_t launch_tile_gather(const float* img, int H, int W, int C, int border, const int* origins, int count,
                               int P, float divisor, float* patches, hipStream_t stream);
 hipError_t launch_recompose(const float* patches, int count, int C, int P, int border, float* img, int H, int W,

@@ -49,13 +49,14 @@ def _to_device_f32(a, device):
 
 
 # ---- interp_patches ---------------------------------------------------------------------------
-def interp_patches_device(image_lr, hr_hw, post_divisor=1.0):
-    """[N,C,h,w] float32 CUDA tensor -> [N,C,H,W]; optionally folds the later ``/= SCALE``."""
+def interp_patches_device(image_lr, hr_hw, post_divisor=1.0, ref=False):
+    """[N,C,h,w] float32 CUDA tensor -> [N,C,H,W]; optionally folds the later ``/= SCALE``.  ref=True: the general
+    kernel whatever the scale (dsen2_upsample_mirror_bilinear_ref, kernel-level cross-check)."""
     n, c, h, w = image_lr.shape
     oh, ow = int(hr_hw[0]), int(hr_hw[1])
     out = torch.empty((n, c, oh, ow), dtype=torch.float32, device=image_lr.device)
     with torch.cuda.device(image_lr.device):
-        _lib.call('dsen2_upsample_mirror_bilinear', _ptr(image_lr), _ptr(out), n * c, h, w, oh, ow,
+        _lib.call('dsen2_upsample_mirror_bilinear_ref' if ref else 'dsen2_upsample_mirror_bilinear', _ptr(image_lr), _ptr(out), n * c, h, w, oh, ow,
                   float(post_divisor), _stream(image_lr.device))
     return out
 

@@ -149,6 +149,10 @@ int dsen2_model_time_body_conv(dsen2_model *m, int layer, const float *dev_in, c
  *   `post_divisor` (1.0 = exact no-op, 2000 folds `p20 /= SCALE`, testing/supres.py:24). */
 int dsen2_upsample_mirror_bilinear(const float *dev_in, float *dev_out, int planes, int h, int w, int oh,
                                    int ow, float post_divisor, void *stream);
+/* The same on the general kernel (any scale; samples fetched on demand) whatever the scale — the windowed kernel that
+ * up-sampling by 2 or more normally takes must give its bits (kernel-level cross-check, like dsen2_conv3x3_nhwc_ref). */
+int dsen2_upsample_mirror_bilinear_ref(const float *dev_in, float *dev_out, int planes, int h, int w, int oh,
+                                       int ow, float post_divisor, void *stream);
 
 /* dsen2_tile_gather  <->  the pad + crop loops of get_test_patches{,60}   patches.py:27-28,58-72 / :93-95,127-143
  *   dev_img: one HWC float32 image [H,W,C] (unpadded); writes patches [count,C,P,P] NCHW where patch k

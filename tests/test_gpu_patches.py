@@ -215,3 +215,22 @@ def test_tiling_geometry_fuzz_matches_oracle(sixty):
         assert np.array_equal(rec, rec_want), tag
         if got[0].shape[0] > 1 and min(d10.shape[:2]) >= patch - 2 * border:
             assert np.array_equal(rec, d10), tag
+
+
+def test_windowed_upsampler_gives_the_general_kernels_bits():
+    """Up-sampling by 2 or more takes the branch-free windowed kernel (all taps loaded at once); the general kernel
+    (dsen2_upsample_mirror_bilinear_ref: taps fetched on demand, any scale) must give the same bits — x2, x3, x6, ragged
+    sizes, mirror edges, one-pixel dims, sizes that are not multiples of a thread's 4 x 8 outputs, both divisors."""
+    import torch
+    from dsen2_amd import patches as P
+    rng = np.random.default_rng(5)
+    for n, c, h, w, oh, ow in [(7, 6, 64, 64, 128, 128), (3, 2, 32, 32, 192, 192), (2, 6, 96, 96, 192, 192), (1, 2, 37, 53, 74, 106),
+                               (2, 3, 1, 1, 2, 2), (1, 1, 2, 3, 12, 18), (1, 2, 10, 10, 27, 27), (2, 1, 5, 7, 15, 21), (1, 1, 33, 1, 66, 5),
+                               (1, 2, 9, 11, 18, 23), (1, 1, 20, 30, 41, 61), (3, 1, 16, 16, 97, 101), (1, 1, 13, 13, 26, 91),
+                               (1, 1, 7, 9, 25, 19), (1, 2, 64, 64, 100, 128)]:
+        x = torch.from_numpy((rng.random((n, c, h, w), dtype=np.float32) * 12000).astype(np.float32)).cuda()
+        x[0, 0, 0, 0] = 0.0
+        for pd in (1.0, 2000.0):
+            a = P.interp_patches_device(x, (oh, ow), post_divisor=pd)
+            b = P.interp_patches_device(x, (oh, ow), post_divisor=pd, ref=True)
+            assert torch.equal(a, b), (n, c, h, w, oh, ow, pd)
