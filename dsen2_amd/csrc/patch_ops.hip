@@ -63,6 +63,16 @@ __device__ __forceinline__ int mirror_index(int i, int dim) {
   return i;
 }
 
+// mirror_index for an index at most one image away (-cmax <= i <= 2 * cmax: one reflection, no division, no branch) —
+// every tap of an up-sampler's window; images of one or two pixels (several reflections) take the general form.
+__device__ __forceinline__ int mirror_index_near(int i, int dim) {
+  const int cmax = dim - 1;
+  int j = i < 0 ? -i : i;
+  j = j > cmax ? 2 * cmax - j : j;
+  if (__builtin_expect((unsigned)j > (unsigned)cmax, 0)) j = mirror_index(i, dim);
+  return j;
+}
+
 // One thread = 4 consecutive output columns x kUpRows consecutive output rows of one plane.  The reference blends
 // horizontally first (top = row r0, bot = row r1, same formula) and then vertically, so the horizontal blend H[r][oj] of
 // an input row is the same number whichever output row asks for it: a thread keeps the two most recent H rows (an
@@ -191,14 +201,14 @@ __global__ __launch_bounds__(256) void upsample_window_kernel(const float* __res
     }
     int wcol[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wcol[j] = mirror_index(cb + j, w);
+    for (int j = 0; j < 4; ++j) wcol[j] = mirror_index_near(cb + j, w);
     // rows: the window starts at the first output row's upper tap
     const int oi0 = rb * kUpRows;
     const int ru0 = (int)floorf(__fadd_rn(__fmul_rn(sy, (float)oi0), oy));
     float q[NR][4];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-      const float* const src = plane + (size_t)mirror_index(ru0 + j, h) * w;
+      const float* const src = plane + (size_t)mirror_index_near(ru0 + j, h) * w;
 #pragma unroll
       for (int c = 0; c < 4; ++c) q[j][c] = src[wcol[c]];
     }
