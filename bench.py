@@ -104,6 +104,17 @@ def main():
         gather_list = [[torch.empty((args.batch, BANDS[-1], H, W), dtype=torch.float32, device=cdev) for _ in range(world)]
                        for _ in range(2)]
     pending = [None, None]
+    # operands of the per-epilogue timings below, allocated NOW: an allocation of 3 x 256 MiB between the timed loop and the
+    # instrumented passes idles the GPU for milliseconds, and it then needs ~25 ms to come back to its steady clock
+    # (profiles/r04_ablation.md §2)
+    bf = cfg['precision'] == 'bf16'
+    rl_a = rl_r = rl_o = None
+    if rank == 0:
+        rl_a = torch.randn((args.batch, H, W, FEAT), dtype=torch.float32, device=dev)
+        rl_r = torch.randn((args.batch, H, W, FEAT), dtype=torch.float32, device=dev)
+        rl_o = torch.empty_like(rl_a)
+        if bf:
+            rl_a = rl_a.to(torch.bfloat16)      # conv-A writes bf16 into `o`; conv-B updates `r` in place, read as the (hi, lo) planes
 
     def step(i):
         """forward of 512 patches into outs[i%2]; then start gathering it to rank 0 (7 peers x 12.6 MB, one xGMI
@@ -163,15 +174,26 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: the 3x3x128x128 body convolution (98.97 % of FLOPs) ----
         pix = args.batch * H * W
-        bf = cfg['precision'] == 'bf16'
-        a = torch.randn((args.batch, H, W, FEAT), dtype=torch.float32, device=dev)
-        r = torch.randn((args.batch, H, W, FEAT), dtype=torch.float32, device=dev)
-        o = torch.empty_like(a)
-        if bf:
-            a = a.to(torch.bfloat16)      # conv-A writes bf16 into `o`; conv-B updates `r` in place, read as the (hi, lo) planes
-        # (1) the launch duration inside the running network: HIP events on the launch stream around the 2d body
-        #     convolutions of `steps` more forward passes on the bench inputs (what rocprofv3 --kernel-trace averages)
-        ms = model.time_body_in_forward(xs, out=outs[0], iters=args.steps)
+        a, r, o = rl_a, rl_r, rl_o
+        # (1) the launch duration inside the running network: `steps` more forward passes on the bench inputs with FOUR HIP
+        #     events each on the launch stream (dsen2_model_forward_profile): whole forward, first convolution, the 2d body
+        #     convolutions, output convolution — consecutive intervals between the same time stamps, so
+        #     launches x ms_per_launch + first_ms + out_ms = forward_ms by construction
+        #     (3 plain passes are enqueued right before them, no synchronisation in between: the GPU is at its steady clock)
+        prof = model.profile_forward(xs, out=outs[0], iters=args.steps, warm=3)
+        ms = prof['body_ms'] / (2 * NUM_LAYERS)
+        # (1b) the same passes WITHOUT the events inside them, right after and equally warm (the kernels run on torch's
+        #     current stream, so two torch events bracket them): what the four event records per forward cost, and whether
+        #     the chip runs the timed loop's step again
+        for _ in range(3):
+            model.forward_device(xs, out=outs[0])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            model.forward_device(xs, out=outs[0])
+        e1.record()
+        torch.cuda.synchronize()
+        replay_ms = e0.elapsed_time(e1) / args.steps
         # (2) each epilogue alone, back to back, on dense random operands (no ReLU zeros: the chip clocks lower)
         ms_relu = model.time_body_conv(1, a, None, o, iters=10)          # conv-A (+bias+ReLU)
         ms_res = model.time_body_conv(2, a, r, o, iters=10)              # conv-B (+bias, *0.1, +residual)
@@ -180,13 +202,22 @@ def main():
         # launch over all 2d of them — then a launch's work and duration are 2d layers'
         launches = model.body_launches(args.batch, H, W)
         per_launch = 2 * NUM_LAYERS // launches
-        traffic, traffic_src = None, None
+        # HBM traffic of that kernel: PMC counters cannot be read in-process, so this is the committed profile of this
+        # config (tools/profile_round.sh -> tools/update_traffic_json.py) — quoted only while the instruction stream it was
+        # measured on is the one this library was built from (dsen2_amd/kernel_isa.json, written by the build)
+        traffic, traffic_src = None, 'no committed PMC profile of this config'
         tj = os.path.join(ROOT, 'profiles', 'body_conv_traffic.json')
+        ij = os.path.join(ROOT, 'dsen2_amd', 'kernel_isa.json')
         if os.path.exists(tj) and args.batch == BATCH:
-            tdat = json.load(open(tj)).get(args.config)     # PMC counters cannot be read in-process: committed profile of this config
-            if tdat:
+            tdat = json.load(open(tj)).get(args.config)
+            built = json.load(open(ij)).get(args.config, {}).get('isa_sha256') if os.path.exists(ij) else None
+            if tdat and built and tdat.get('isa_sha256') == built:
                 traffic, traffic_src = tdat['traffic_bytes'], tdat['source']
+            elif tdat:
+                traffic_src = 'STALE, not quoted: profiles/body_conv_traffic.json was measured on kernel ISA %s, this build is %s' % (
+                    str(tdat.get('isa_sha256'))[:12], str(built)[:12])
         achieved = flops / (ms * 1e-3) / 1e12
+        closure = launches * ms * per_launch + prof['first_ms'] + prof['out_ms']
         result['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK,
                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK, 4), 'traffic': traffic,
                               'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
@@ -196,11 +227,23 @@ def main():
                                   FEAT, FEAT, 'bf16 MFMA 16x16x32, LDS-DMA staging, 16x32-pixel items' if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging',
                                   '; ONE launch over all %d body convolutions, a workgroup owns its patches through every layer' % (2 * NUM_LAYERS) if launches == 1 else ''),
                               'ms_per_launch': round(ms * per_launch, 4),
-                              'ms_per_launch_source': 'HIP events around the %d body-conv launch%s of %d forward passes' % (launches, '' if launches == 1 else 'es', args.steps),
+                              'ms_per_launch_source': 'HIP events on the launch stream around the %d body-conv launch%s of each of %d forward passes (4 events per pass)' % (launches, '' if launches == 1 else 'es', args.steps),
                               'launches_per_forward': launches, 'convolutions_per_launch': per_launch, 'ms_per_convolution': round(ms, 4),
+                              # the line closes on itself: launches x ms_per_launch + first_ms + out_ms = forward_ms (same events)
+                              'forward_ms': round(prof['forward_ms'], 4), 'first_ms': round(prof['first_ms'], 4),
+                              'out_ms': round(prof['out_ms'], 4), 'closure_ms': round(closure, 4),
+                              # ... and against the un-instrumented step: forward_period_ms = one instrumented pass with
+                              # its four event records and the gap to the next pass; replay_ms_per_step = the same passes
+                              # without those events, right after, equally warm; event_cost_ms = their difference;
+                              # replay_vs_timed_loop_ms = replay minus the timed loop's ms_per_step (which also holds the
+                              # bracketing synchronisations and, at N > 1, the gather): ~0 when the chip runs the same clock
+                              'forward_period_ms': round(prof['wall_ms'], 4), 'replay_ms_per_step': round(replay_ms, 4),
+                              'event_cost_ms': round(prof['wall_ms'] - replay_ms, 4),
+                              'replay_vs_timed_loop_ms': round(replay_ms - ms_per_step, 4),
                               'ms_relu_randn': round(ms_relu, 4), 'ms_residual_randn': round(ms_res, 4),
                               'flop_per_launch': flops * per_launch}
         del a, r, o
+        rl_a = rl_r = rl_o = None
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'dsen2_20_fp32':
         # ---- CPU baseline: the same graph on the host cores, bounded sample (oracle/ = checker code) ----

@@ -137,6 +137,22 @@ class S2Model(object):
                       _ptr(ws), ws.numel(), _stream_ptr(self.device), int(iters), ctypes.byref(ms))
         return ms.value
 
+    def profile_forward(self, xs, out=None, iters=10, warm=3):
+        """`warm` plain forward passes, then — the stream never idling in between — `iters` passes on `xs` with four HIP
+        events each (dsen2_model_forward_profile).  Mean milliseconds: forward_ms (first event to last of a pass), first_ms /
+        body_ms / out_ms (first convolution, all 2*num_layers residual-block convolutions, output convolution: consecutive
+        intervals, they add up to forward_ms) and wall_ms (per instrumented pass, first event of the first pass to last event
+        of the last: a pass with its event records and the gap to the next one)."""
+        n, _, h, w = xs[0].shape
+        out = self._check_out(out, n, h, w)
+        ws = self._get_workspace(self.workspace_bytes(n, h, w))
+        ms = (ctypes.c_float * 5)()
+        with torch.cuda.device(self.device):
+            _lib.call('dsen2_model_forward_profile', self._handle, _ptr(xs[0]), _ptr(xs[1]),
+                      _ptr(xs[2]) if len(xs) == 3 else ctypes.c_void_p(0), _ptr(out), n, h, w,
+                      _ptr(ws), ws.numel(), _stream_ptr(self.device), int(warm), int(iters), ms)
+        return dict(forward_ms=ms[0], first_ms=ms[1], body_ms=ms[2], out_ms=ms[3], wall_ms=ms[4])
+
     def body_launches(self, n, h, w):
         """Kernel launches the 2*num_layers residual-block convolutions of a batch take: 1 = one chain launch."""
         with torch.cuda.device(self.device):

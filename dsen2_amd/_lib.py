@@ -5,6 +5,7 @@ raised.  Nothing in this package computes on the CPU.
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DSEN2_HIP_LIB') or os.path.join(_HERE, 'libdsen2_hip.so')   # override: A/B of experimental builds
@@ -33,6 +34,8 @@ SIGNATURES = {
     'dsen2_model_body_launches': (c_int, [c_void_p, c_int, c_int, c_int]),
     'dsen2_model_forward_timed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_void_p, c_size_t, c_void_p, c_int, c_float_p]),
+    'dsen2_model_forward_profile': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                            c_void_p, c_size_t, c_void_p, c_int, c_int, c_float_p]),
     'dsen2_conv3x3_nhwc': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_int, c_int, ctypes.c_float, c_void_p]),
     'dsen2_conv3x3_nhwc_ref': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -73,6 +76,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError('%s not found: build it with `python -m dsen2_amd.build` (hipcc, gfx950). '
                               'dsen2_amd has no CPU fallback.' % LIB_PATH)
+        if os.environ.get('DSEN2_HIP_LIB'):
+            # the override exists for tools/ (A/B of experimental and diagnostic builds, whose outputs can be wrong under
+            # ablation masks): never silently
+            sys.stderr.write('dsen2_amd: DSEN2_HIP_LIB overrides the product library: loading %s\n' % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported

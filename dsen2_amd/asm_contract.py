@@ -110,6 +110,22 @@ def check_listing(text, src):
             for g in range(0, len(mf), STEP_MFMAS):
                 inner = body[mf[g]:mf[g + STEP_MFMAS - 1]]
                 need(not any('scratch_' in ln for ln in inner), 'chain kernel %s spills inside an item body' % name)
+            # ... and a scratch access outside the item bodies must sit in a DRAINED region: it is a vector-memory
+            # operation the hand counts do not know, so a counted wait (vmcnt(k > 0)) that follows it would retire one
+            # operation fewer of the epilogue it targets.  Required: after every scratch access the next vmcnt wait in the
+            # listing is vmcnt(0), and it comes before the next MFMA.
+            for i, ln in enumerate(body):
+                if 'scratch_' not in ln:
+                    continue
+                nxt = None
+                for ln2 in body[i + 1:]:
+                    if ln2.startswith('v_mfma'):
+                        break
+                    mm = re.search(r'vmcnt\((\d+)\)', ln2) if ln2.startswith('s_waitcnt') else None
+                    if mm:
+                        nxt = int(mm.group(1))
+                        break
+                need(nxt == 0, 'chain kernel %s: scratch access outside a drained region (next vmcnt wait: %r)' % (name, nxt), [ln])
         back = [ln for ln in body[-40:] if ln.startswith('s_waitcnt') and 'vmcnt' in ln]
         need(back and back[-1].replace(' ', '') in ('s_waitcntvmcnt(0)', 's_waitcntvmcnt(0)lgkmcnt(0)'),
              'kernel %s does not drain its DMAs before s_endpgm' % name, back[-3:])
@@ -167,7 +183,43 @@ def check_out_mfma_listing(text, src='conv3x3_out_mfma.hip'):
     return True
 
 
-def check_sources(hipcc, flags, verbose=False):
+# The kernels whose measured HBM traffic bench.py quotes from profiles/body_conv_traffic.json (PMC counters cannot be read
+# in-process): config -> (source file, regular expression on the mangled name).  Their ISA hash is written next to the
+# library at build time (kernel_isa.json) and next to the traffic figure when tools/update_traffic_json.py records it, so
+# bench.py can refuse a figure measured on another instruction stream.
+TRAFFIC_KERNELS = {
+    'dsen2_20_fp32': ('conv3x3_body32.hip', r'conv3x3_body32_kernelILi128ELi128ELi0ELi0ELi0ELb1ELb1E'),
+    'vdsen2_20_bf16': ('conv3x3_body16w.hip', r'conv3x3_body16w_chain_kernelILi128ELi256ELi0E'),
+}
+ISA_JSON = os.path.join(HERE, 'kernel_isa.json')
+
+
+def isa_hashes(text):
+    """mangled kernel name -> sha256 of its instruction list (local labels and whitespace normalised)."""
+    import hashlib
+    out = {}
+    for name, body in _kernels(text).items():
+        norm = [re.sub(r'\.L\w+', 'L', re.sub(r'\s+', ' ', ln)) for ln in body]
+        out[name] = hashlib.sha256('\n'.join(norm).encode()).hexdigest()
+    return out
+
+
+def traffic_kernel_hashes(listings):
+    """listings: source file -> ISA text.  config -> {'kernel': mangled name, 'isa_sha256': ...} for TRAFFIC_KERNELS."""
+    out = {}
+    for cfg, (src, pat) in TRAFFIC_KERNELS.items():
+        hits = {k: v for k, v in isa_hashes(listings[src]).items() if re.search(pat, k)}
+        if len(hits) != 1:
+            raise AsmContractError('%s: expected one kernel matching %s, found %d' % (src, pat, len(hits)))
+        (k, v), = hits.items()
+        out[cfg] = {'kernel': k, 'isa_sha256': v}
+    return out
+
+
+def check_sources(hipcc, flags, verbose=False, isa_json=None):
+    """Compiles the contract's translation units to ISA and checks them; returns traffic_kernel_hashes() of what it has
+    compiled (and writes it to `isa_json` when given: dsen2_amd.build does, next to the library)."""
+    listings = {}
     with tempfile.TemporaryDirectory(prefix='dsen2_asm_') as tmp:
         for src in DMA_SOURCES + ['conv3x3_out_mfma.hip']:
             out = os.path.join(tmp, src + '.s')
@@ -176,8 +228,15 @@ def check_sources(hipcc, flags, verbose=False):
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
             with open(out) as f:
-                if src in DMA_SOURCES:
-                    check_listing(f.read(), src)
-                else:
-                    check_out_mfma_listing(f.read(), src)
-    return True
+                listings[src] = f.read()
+            if src in DMA_SOURCES:
+                check_listing(listings[src], src)
+            else:
+                check_out_mfma_listing(listings[src], src)
+    hashes = traffic_kernel_hashes(listings)
+    if isa_json:
+        import json
+        with open(isa_json, 'w') as f:
+            json.dump(hashes, f, indent=1, sort_keys=True)
+            f.write('\n')
+    return hashes

@@ -23,8 +23,10 @@ DIAG_LIB = os.path.join(os.path.dirname(HERE), 'build', 'libdsen2_hip_diag.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators, so the default contraction would fuse the
 # up-sampler's `scale*dst + offset` (skimage rounds twice) and the residual epilogue's `x + 0.1*t` into FMAs.
+# -Werror=array-bounds: an out-of-range constant index into a register array is silently "undefined" (the archived
+# single-copy fp32 chain computed with whatever the registers held: profiles/r04_ablation.md §1).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-ffp-contract=off',
-         '-Wall', '-Wno-unused-function']
+         '-Wall', '-Wno-unused-function', '-Werror=array-bounds']
 JOBS = int(os.environ.get('DSEN2_BUILD_JOBS', '4'))      # translation units compiled side by side
 
 
@@ -61,7 +63,7 @@ def build(force=False, verbose=False, diag=False):
         if not diag:
             from . import asm_contract
             try:
-                asm_contract.check_sources(HIPCC, FLAGS, verbose=verbose)
+                asm_contract.check_sources(HIPCC, FLAGS, verbose=verbose, isa_json=asm_contract.ISA_JSON)
             except Exception:
                 os.unlink(lib + '.tmp')
                 raise

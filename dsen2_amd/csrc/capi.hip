@@ -3,9 +3,11 @@
 // launch sequence of one forward pass.  No torch types, no allocation inside the forward path.
 #include "../../include/dsen2_hip.h"
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <vector>
 
@@ -23,6 +25,22 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+// Nothing may leave an extern "C" entry point as a C++ exception (std::bad_alloc from a staging vector, std::system_error
+// from a mutex): through a C / ctypes caller that is std::terminate -> abort() of the host process.  Every entry point
+// that can allocate or lock runs its body through this and reports DSEN2_ERR_* with dsen2_last_error() instead.
+template <class F>
+int guarded(F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return fail(DSEN2_ERR_INVALID, "out of host memory");
+  } catch (const std::exception& e) {
+    return fail(DSEN2_ERR_INVALID, "unexpected C++ exception: %s", e.what());
+  } catch (...) {
+    return fail(DSEN2_ERR_INVALID, "unexpected C++ exception");
+  }
 }
 
 #define HIP_TRY(expr)                                                                          \
@@ -56,6 +74,7 @@ Tuning default_tuning() {
 #endif
 }
 
+constexpr int kWarmLaunches = 24;      // dsen2_model_time_body_conv: untimed launches before the timed ones
 constexpr size_t kAlignFloats = 64;   // 256-byte alignment of every device sub-buffer
 size_t align_up(size_t v) { return (v + kAlignFloats - 1) / kAlignFloats * kAlignFloats; }
 
@@ -72,6 +91,17 @@ struct dsen2_model {
   float* dev_params;
   bool loaded;
 };
+
+// A handle belongs to the device that was current when it was created (its packed weights live there): a call made with
+// another current device would hand device A's pointers to kernels launched on device B.
+static int check_device(const dsen2_model* m) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(DSEN2_ERR_NO_DEVICE, "no HIP device");
+  if (dev != m->device)
+    return fail(DSEN2_ERR_INVALID, "model handle belongs to device %d but the calling thread's current device is %d "
+                "(one handle per device: hipSetDevice(%d) before the call)", m->device, dev, m->device);
+  return DSEN2_OK;
+}
 
 extern "C" {
 
@@ -144,7 +174,7 @@ int dsen2_device_count(void) {
   return good;
 }
 
-int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_layers, int feature_size,
+static int model_create_unguarded(dsen2_model** out, int c10, int c20, int c60, int num_layers, int feature_size,
                        int precision) {
   if (!out) return fail(DSEN2_ERR_INVALID, "out is NULL");
   *out = nullptr;
@@ -214,10 +244,11 @@ void dsen2_model_destroy(dsen2_model* m) {
 
 size_t dsen2_model_num_params(const dsen2_model* m) { return m ? m->n_params : 0; }
 
-int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t count) {
+static int model_load_weights_unguarded(dsen2_model* m, const float* host_flat, size_t count) {
   if (!m || !host_flat) return fail(DSEN2_ERR_INVALID, "NULL argument");
   if (count != m->n_params)
     return fail(DSEN2_ERR_INVALID, "expected %zu parameters, got %zu", m->n_params, count);
+  if (int rc = check_device(m)) return rc;      // the packed weights are allocated on the current device
   std::vector<float> staged(m->dev_param_floats, 0.f);
   for (const Layer& L : m->layers) {
     const float* k = host_flat + L.flat_off;
@@ -266,15 +297,18 @@ static ConvParams make_params(const float* in, const float* wpk, const float* bi
   return p;
 }
 
-// ev_body0 / ev_body1 (optional): recorded on the stream right before the first and right after the last
-// residual-block convolution
+// ev (optional, 4 events): recorded on the stream before the first convolution, before the first and after the last
+// residual-block convolution, and after the output convolution
 static int forward_impl(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
-                        int h, int w, void* workspace, size_t workspace_bytes, void* stream_, hipEvent_t ev_body0,
-                        hipEvent_t ev_body1) {
+                        int h, int w, void* workspace, size_t workspace_bytes, void* stream_, const hipEvent_t* ev) {
   if (!m || !x10 || !x20 || !out || !workspace) return fail(DSEN2_ERR_INVALID, "NULL argument");
+  const hipEvent_t ev_fwd0 = ev ? ev[0] : nullptr, ev_body0 = ev ? ev[1] : nullptr, ev_body1 = ev ? ev[2] : nullptr,
+                   ev_fwd1 = ev ? ev[3] : nullptr;
   if ((m->c60 > 0) != (x60 != nullptr)) return fail(DSEN2_ERR_INVALID, "x60 must be given iff the model has a 60 m input");
   if (!m->loaded) return fail(DSEN2_ERR_NO_WEIGHTS, "dsen2_model_load_weights has not been called");
   int rc = check_shape(m, n, h, w);
+  if (rc) return rc;
+  rc = check_device(m);
   if (rc) return rc;
   size_t need = 0;
   dsen2_model_workspace_bytes(m, n, h, w, &need);
@@ -290,6 +324,7 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
   const int abl = m->tune.ablate;
   size_t li = 0;
   const bool planes = m->precision == 1 && m->num_layers > 0;
+  if (ev_fwd0) HIP_TRY(hipEventRecord(ev_fwd0, stream));
   {
     const Layer& L = m->layers[li++];            // DSen2Net.py:24-29: Concatenate + Conv2D + ReLU
     ConvParams pf = make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f);
@@ -373,12 +408,15 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
 #endif
     HIP_TRY(launch_conv3x3(po, L.geom, L.epilogue, m->tune.out_ablate, stream));
   }
+  if (ev_fwd1) HIP_TRY(hipEventRecord(ev_fwd1, stream));
   return DSEN2_OK;
 }
 
-int dsen2_model_body_launches(const dsen2_model* m, int n, int h, int w) {
+static int model_body_launches_unguarded(const dsen2_model* m, int n, int h, int w) {
   if (!m) return fail(DSEN2_ERR_INVALID, "NULL model");
   int rc = check_shape(m, n, h, w);
+  if (rc) return rc;
+  rc = check_device(m);
   if (rc) return rc;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -388,33 +426,89 @@ int dsen2_model_body_launches(const dsen2_model* m, int n, int h, int w) {
   return chain ? 1 : 2 * m->num_layers;
 }
 
-int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
+static int model_forward_unguarded(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
                         int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
-  return forward_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, nullptr, nullptr);
+  return forward_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, nullptr);
 }
 
-int dsen2_model_forward_timed(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
+// `iters` forward passes with four events each (forward_impl); ms[0..3] = mean of (whole forward, first convolution,
+// all residual-block convolutions, output convolution) — three consecutive intervals between the same four time stamps,
+// so ms[1] + ms[2] + ms[3] = ms[0] by construction; ms[4] = host wall-clock per pass of this instrumented run (enqueue
+// of the first pass to completion of the last, / iters): what the events themselves cost shows as ms[4] against an
+// un-instrumented loop of the same passes.
+//
+// `warm` un-instrumented passes are enqueued right before the instrumented ones, with no synchronisation in between: after
+// any idle stretch of a few milliseconds (a host-side allocation, a synchronisation followed by host work) this GPU needs
+// ~25 launches of the body convolution (~25 ms) to come back to its steady clock — launches are up to 16 % slower meanwhile
+// (profiles/r04_ablation.md §2: the per-dispatch timeline) — so intervals measured cold are not the running network's.
+static int forward_profile_impl(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
+                                int h, int w, void* workspace, size_t workspace_bytes, void* stream, int warm, int iters,
+                                float* ms) {
+  if (iters <= 0 || iters > 4096 || warm < 0 || warm > 4096 || !ms) return fail(DSEN2_ERR_INVALID, "bad warm / iters / NULL result");
+  if (!m) return fail(DSEN2_ERR_INVALID, "NULL model");
+  // the events are destroyed on every path
+  struct Events {
+    std::vector<hipEvent_t> ev;
+    ~Events() {
+      for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    }
+  } evs;
+  evs.ev.assign(4 * (size_t)iters, nullptr);
+  for (hipEvent_t& e : evs.ev) HIP_TRY(hipEventCreate(&e));
+  for (int i = 0; i < warm; ++i) {
+    int rc = forward_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, nullptr);
+    if (rc != DSEN2_OK) return rc;
+  }
+  // (the host clock starts when the warm passes are enqueued, not when they finish: a synchronisation here would be the
+  // idle stretch the warm passes exist to avoid; ms[4] is corrected for them below)
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) {
+    int rc = forward_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, &evs.ev[4 * (size_t)i]);
+    if (rc != DSEN2_OK) {
+      (void)hipStreamSynchronize((hipStream_t)stream);     // nothing recorded may outlive its event
+      return rc;
+    }
+  }
+  HIP_TRY(hipEventSynchronize(evs.ev.back()));
+  const auto t1 = std::chrono::steady_clock::now();
+  double sum[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < iters; ++i) {
+    const hipEvent_t* e = &evs.ev[4 * (size_t)i];
+    float v = 0.f;
+    HIP_TRY(hipEventElapsedTime(&v, e[0], e[3])); sum[0] += v;
+    HIP_TRY(hipEventElapsedTime(&v, e[0], e[1])); sum[1] += v;
+    HIP_TRY(hipEventElapsedTime(&v, e[1], e[2])); sum[2] += v;
+    HIP_TRY(hipEventElapsedTime(&v, e[2], e[3])); sum[3] += v;
+  }
+  for (int k = 0; k < 4; ++k) ms[k] = (float)(sum[k] / iters);
+  // host wall clock per instrumented pass: enqueue of the first instrumented pass to completion of the last one; when warm
+  // passes are still running at t0, the interval from the first instrumented event (GPU clock) is the truthful one
+  double wall = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  if (warm > 0) {
+    float span = 0.f;
+    HIP_TRY(hipEventElapsedTime(&span, evs.ev.front(), evs.ev.back()));
+    wall = span;
+  }
+  ms[4] = (float)(wall / iters);
+  return DSEN2_OK;
+}
+
+static int model_forward_timed_unguarded(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n,
                               int h, int w, void* workspace, size_t workspace_bytes, void* stream, int iters,
                               float* body_ms_per_launch) {
-  if (iters <= 0 || iters > 4096 || !body_ms_per_launch) return fail(DSEN2_ERR_INVALID, "bad iters / NULL result");
+  if (!body_ms_per_launch) return fail(DSEN2_ERR_INVALID, "NULL result");
   if (!m || m->num_layers <= 0) return fail(DSEN2_ERR_INVALID, "model has no residual blocks");
-  std::vector<hipEvent_t> ev(2 * (size_t)iters, nullptr);
-  int rc = DSEN2_OK;
-  for (size_t i = 0; i < ev.size() && rc == DSEN2_OK; ++i)
-    if (hipEventCreate(&ev[i]) != hipSuccess) rc = fail(DSEN2_ERR_HIP, "hipEventCreate failed");
-  for (int i = 0; i < iters && rc == DSEN2_OK; ++i)
-    rc = forward_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, ev[2 * i], ev[2 * i + 1]);
-  double total = 0.0;
-  if (rc == DSEN2_OK && hipEventSynchronize(ev.back()) != hipSuccess) rc = fail(DSEN2_ERR_HIP, "hipEventSynchronize failed");
-  for (int i = 0; i < iters && rc == DSEN2_OK; ++i) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = fail(DSEN2_ERR_HIP, "hipEventElapsedTime failed");
-    total += ms;
-  }
-  for (hipEvent_t e : ev)
-    if (e) (void)hipEventDestroy(e);
-  if (rc == DSEN2_OK) *body_ms_per_launch = (float)(total / iters / (2.0 * m->num_layers));
+  float ms[5];
+  int rc = forward_profile_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, 0, iters, ms);
+  if (rc == DSEN2_OK) *body_ms_per_launch = ms[2] / (2.0f * m->num_layers);
   return rc;
+}
+
+static int model_forward_profile_unguarded(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out,
+                                           int n, int h, int w, void* workspace, size_t workspace_bytes, void* stream,
+                                           int warm, int iters, float* ms5) {
+  return forward_profile_impl(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, warm, iters, ms5);
 }
 
 static int conv3x3_nhwc_impl(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
@@ -444,14 +538,14 @@ static int conv3x3_nhwc_impl(const float* dev_in, const float* host_kernel, cons
   return DSEN2_OK;
 }
 
-int dsen2_conv3x3_nhwc(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
+static int conv3x3_nhwc_unguarded(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
                        float* dev_out, int n, int h, int w, int cin, int cout, int epilogue, float res_scale,
                        void* stream) {
   return conv3x3_nhwc_impl(dev_in, host_kernel, host_bias, dev_aux, dev_out, n, h, w, cin, cout, epilogue, res_scale,
                            stream, default_tuning());
 }
 
-int dsen2_conv3x3_nhwc_ref(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
+static int conv3x3_nhwc_ref_unguarded(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux,
                            float* dev_out, int n, int h, int w, int cin, int cout, int epilogue, float res_scale,
                            void* stream) {
   Tuning ref;                 // the one-tile-per-workgroup kernels of conv3x3_mfma.hip for every layer shape
@@ -461,7 +555,7 @@ int dsen2_conv3x3_nhwc_ref(const float* dev_in, const float* host_kernel, const 
                            stream, ref);
 }
 
-int dsen2_split_f32(const float* dev_in, void* dev_hi, void* dev_lo, int n, int h, int w, int c, void* stream) {
+static int split_f32_unguarded(const float* dev_in, void* dev_hi, void* dev_lo, int n, int h, int w, int c, void* stream) {
   if (!dev_in || !dev_hi || !dev_lo || n < 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 != 0 || c > 512)
     return fail(DSEN2_ERR_INVALID, "bad argument (c must be a multiple of 8, at most 512)");
   if (n == 0) return DSEN2_OK;
@@ -469,7 +563,7 @@ int dsen2_split_f32(const float* dev_in, void* dev_hi, void* dev_lo, int n, int 
   return DSEN2_OK;
 }
 
-int dsen2_join_f32(const void* dev_hi, const void* dev_lo, float* dev_out, int n, int h, int w, int c, void* stream) {
+static int join_f32_unguarded(const void* dev_hi, const void* dev_lo, float* dev_out, int n, int h, int w, int c, void* stream) {
   if (!dev_out || !dev_hi || !dev_lo || n < 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 != 0 || c > 512)
     return fail(DSEN2_ERR_INVALID, "bad argument (c must be a multiple of 8, at most 512)");
   if (n == 0) return DSEN2_OK;
@@ -477,7 +571,7 @@ int dsen2_join_f32(const void* dev_hi, const void* dev_lo, float* dev_out, int n
   return DSEN2_OK;
 }
 
-int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, const float* host_bias, void* dev_res_hi,
+static int conv3x3_body_bf16_unguarded(const void* dev_in_bf16, const float* host_kernel, const float* host_bias, void* dev_res_hi,
                             void* dev_res_lo, void* dev_out, int n, int h, int w, int feat, int epilogue,
                             float res_scale, void* stream_) {
   if (!dev_in_bf16 || !host_kernel || !host_bias) return fail(DSEN2_ERR_INVALID, "NULL argument");
@@ -508,12 +602,14 @@ int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, c
   return DSEN2_OK;
 }
 
-int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, const float* dev_aux, float* dev_out,
+static int model_time_body_conv_unguarded(dsen2_model* m, int layer, const float* dev_in, const float* dev_aux, float* dev_out,
                                int n, int h, int w, int iters, void* stream_, float* ms_per_launch) {
   if (!m || !dev_in || !dev_out || !ms_per_launch || iters <= 0) return fail(DSEN2_ERR_INVALID, "bad argument");
   if (!m->loaded) return fail(DSEN2_ERR_NO_WEIGHTS, "weights not loaded");
   if (layer < 1 || layer > 2 * m->num_layers) return fail(DSEN2_ERR_INVALID, "layer %d out of range", layer);
   int rc = check_shape(m, n, h, w);
+  if (rc) return rc;
+  rc = check_device(m);
   if (rc) return rc;
   const Layer& L = m->layers[layer];
   if (L.epilogue == kEpiResidual && !dev_aux) return fail(DSEN2_ERR_INVALID, "residual layer needs dev_aux");
@@ -546,7 +642,8 @@ int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, c
   } ev;
   HIP_TRY(hipEventCreate(&ev.e0));
   HIP_TRY(hipEventCreate(&ev.e1));
-  HIP_TRY(launch());   // warm-up
+  // warm-up: ~25 ms of this kernel bring the chip back to its steady clock after an idle stretch (see forward_profile_impl)
+  for (int i = 0; i < kWarmLaunches; ++i) HIP_TRY(launch());
   HIP_TRY(hipEventRecord(ev.e0, stream));
   for (int i = 0; i < iters; ++i) HIP_TRY(launch());
   HIP_TRY(hipEventRecord(ev.e1, stream));
@@ -568,17 +665,17 @@ static int upsample_impl(const float* dev_in, float* dev_out, int planes, int h,
   return DSEN2_OK;
 }
 
-int dsen2_upsample_mirror_bilinear(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow,
+static int upsample_mirror_bilinear_unguarded(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow,
                                    float post_divisor, void* stream) {
   return upsample_impl(dev_in, dev_out, planes, h, w, oh, ow, post_divisor, stream, false);
 }
 
-int dsen2_upsample_mirror_bilinear_ref(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow,
+static int upsample_mirror_bilinear_ref_unguarded(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow,
                                        float post_divisor, void* stream) {
   return upsample_impl(dev_in, dev_out, planes, h, w, oh, ow, post_divisor, stream, true);
 }
 
-int dsen2_tile_gather(const float* dev_img, int H, int W, int C, int border, const int* dev_origins, int count, int P,
+static int tile_gather_unguarded(const float* dev_img, int H, int W, int C, int border, const int* dev_origins, int count, int P,
                       float divisor, float* dev_patches, void* stream) {
   if (!dev_img || !dev_patches || (!dev_origins && count > 0) || H <= 0 || W <= 0 || C <= 0 || border < 0 ||
       count < 0 || P <= 0 || divisor == 0.f)
@@ -589,7 +686,7 @@ int dsen2_tile_gather(const float* dev_img, int H, int W, int C, int border, con
   return DSEN2_OK;
 }
 
-int dsen2_recompose(const float* dev_patches, int count, int C, int P, int border, float* dev_img, int H, int W,
+static int recompose_unguarded(const float* dev_patches, int count, int C, int P, int border, float* dev_img, int H, int W,
                     float scale, void* stream) {
   if (!dev_patches || !dev_img || count <= 0 || C <= 0 || P <= 0 || border < 0 || H <= 0 || W <= 0)
     return fail(DSEN2_ERR_INVALID, "bad argument");
@@ -598,6 +695,56 @@ int dsen2_recompose(const float* dev_patches, int count, int C, int P, int borde
     return fail(DSEN2_ERR_INVALID, "recompose geometry: count=%d P=%d border=%d H=%d W=%d", count, P, border, H, W);
   if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "recompose launch: %s", hipGetErrorString(e));
   return DSEN2_OK;
+}
+
+// ---- the exported forms of the entry points above: no C++ exception crosses the ABI (guarded(), top of this file) ----
+int dsen2_model_create(dsen2_model** out, int c10, int c20, int c60, int num_layers, int feature_size, int precision) {
+  return guarded([&] { return model_create_unguarded(out, c10, c20, c60, num_layers, feature_size, precision); });
+}
+int dsen2_model_load_weights(dsen2_model* m, const float* host_flat, size_t count) {
+  return guarded([&] { return model_load_weights_unguarded(m, host_flat, count); });
+}
+int dsen2_model_forward(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+  return guarded([&] { return model_forward_unguarded(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream); });
+}
+int dsen2_model_forward_timed(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n, int h, int w, void* workspace, size_t workspace_bytes, void* stream, int iters, float* body_ms_per_launch) {
+  return guarded([&] { return model_forward_timed_unguarded(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, iters, body_ms_per_launch); });
+}
+int dsen2_model_forward_profile(dsen2_model* m, const float* x10, const float* x20, const float* x60, float* out, int n, int h, int w, void* workspace, size_t workspace_bytes, void* stream, int warm, int iters, float* ms5) {
+  return guarded([&] { return model_forward_profile_unguarded(m, x10, x20, x60, out, n, h, w, workspace, workspace_bytes, stream, warm, iters, ms5); });
+}
+int dsen2_conv3x3_nhwc(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux, float* dev_out, int n, int h, int w, int cin, int cout, int epilogue, float res_scale, void* stream) {
+  return guarded([&] { return conv3x3_nhwc_unguarded(dev_in, host_kernel, host_bias, dev_aux, dev_out, n, h, w, cin, cout, epilogue, res_scale, stream); });
+}
+int dsen2_conv3x3_nhwc_ref(const float* dev_in, const float* host_kernel, const float* host_bias, const float* dev_aux, float* dev_out, int n, int h, int w, int cin, int cout, int epilogue, float res_scale, void* stream) {
+  return guarded([&] { return conv3x3_nhwc_ref_unguarded(dev_in, host_kernel, host_bias, dev_aux, dev_out, n, h, w, cin, cout, epilogue, res_scale, stream); });
+}
+int dsen2_split_f32(const float* dev_in, void* dev_hi, void* dev_lo, int n, int h, int w, int c, void* stream) {
+  return guarded([&] { return split_f32_unguarded(dev_in, dev_hi, dev_lo, n, h, w, c, stream); });
+}
+int dsen2_join_f32(const void* dev_hi, const void* dev_lo, float* dev_out, int n, int h, int w, int c, void* stream) {
+  return guarded([&] { return join_f32_unguarded(dev_hi, dev_lo, dev_out, n, h, w, c, stream); });
+}
+int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, const float* host_bias, void* dev_res_hi, void* dev_res_lo, void* dev_out, int n, int h, int w, int feat, int epilogue, float res_scale, void* stream_) {
+  return guarded([&] { return conv3x3_body_bf16_unguarded(dev_in_bf16, host_kernel, host_bias, dev_res_hi, dev_res_lo, dev_out, n, h, w, feat, epilogue, res_scale, stream_); });
+}
+int dsen2_model_time_body_conv(dsen2_model* m, int layer, const float* dev_in, const float* dev_aux, float* dev_out, int n, int h, int w, int iters, void* stream_, float* ms_per_launch) {
+  return guarded([&] { return model_time_body_conv_unguarded(m, layer, dev_in, dev_aux, dev_out, n, h, w, iters, stream_, ms_per_launch); });
+}
+int dsen2_upsample_mirror_bilinear(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow, float post_divisor, void* stream) {
+  return guarded([&] { return upsample_mirror_bilinear_unguarded(dev_in, dev_out, planes, h, w, oh, ow, post_divisor, stream); });
+}
+int dsen2_upsample_mirror_bilinear_ref(const float* dev_in, float* dev_out, int planes, int h, int w, int oh, int ow, float post_divisor, void* stream) {
+  return guarded([&] { return upsample_mirror_bilinear_ref_unguarded(dev_in, dev_out, planes, h, w, oh, ow, post_divisor, stream); });
+}
+int dsen2_tile_gather(const float* dev_img, int H, int W, int C, int border, const int* dev_origins, int count, int P, float divisor, float* dev_patches, void* stream) {
+  return guarded([&] { return tile_gather_unguarded(dev_img, H, W, C, border, dev_origins, count, P, divisor, dev_patches, stream); });
+}
+int dsen2_recompose(const float* dev_patches, int count, int C, int P, int border, float* dev_img, int H, int W, float scale, void* stream) {
+  return guarded([&] { return recompose_unguarded(dev_patches, count, C, P, border, dev_img, H, W, scale, stream); });
+}
+int dsen2_model_body_launches(const dsen2_model* m, int n, int h, int w) {
+  return guarded([&] { return model_body_launches_unguarded(m, n, h, w); });
 }
 
 }  // extern "C"

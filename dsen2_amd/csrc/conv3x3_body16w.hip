@@ -121,8 +121,10 @@ constexpr int younger_than_input(bool has_w) { return has_w ? 4 * W_PER_STEP : 0
 //     for >= 2 patches per workgroup (a patch's items of consecutive layers are then >= 2 positions apart) and for one
 //     patch per workgroup at F = 256 (the only distance-1 pair is last item = (last tile, slab 1) -> first item, and
 //     slab 1 is input chunks 4-7).  In-kernel stamps (tools/stamp_chain.py): 2.0-2.4 k cycles per boundary.
-//   * DRAINED otherwise (F = 128 with one patch per workgroup): every wave retires everything (vmcnt(0)), barrier, the
-//     next layer's first input chunk is staged and awaited: 6-11 k cycles per boundary.
+//   * DRAINED otherwise (F = 128 with one patch in THIS workgroup — a launch of one patch per workgroup, or the tail
+//     workgroup of a batch that patches_per_wg does not divide; decided per workgroup from the patches it owns): every
+//     wave retires everything (vmcnt(0)), barrier, the next layer's first input chunk is staged and awaited: 6-11 k
+//     cycles per boundary.
 // EPI is chosen per layer: conv-A (even) kEpiRelu hi -> t, conv-B (odd) kEpiResidual in place on (hi, lo), the last
 // one kEpiResidualF32 -> out_f32 — three instantiations of the item loop in one kernel.  Same arithmetic per item as the
 // per-layer kernels: same bits.  Diagnostic masks of the chain kernel: 1024 drained boundaries everywhere, 2048 (timing
@@ -169,11 +171,13 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
   float RS_ = p.res_scale;
   // items this workgroup walks (per layer): item0, item0 + istep, ... (my_items of them)
   int item0, my_items;
+  int my_imgs = 0;                           // CHAIN: whole patches this workgroup owns (the tail workgroup may own fewer)
   const int istep = CHAIN ? 1 : G;
   if constexpr (CHAIN) {
     const int first_img = lid * chain.patches_per_wg;
     const int imgs = p.n - first_img < chain.patches_per_wg ? p.n - first_img : chain.patches_per_wg;
     if (imgs <= 0) return;
+    my_imgs = imgs;
     item0 = first_img * TPI_ * NS;
     my_items = imgs * TPI_ * NS;
   } else {
@@ -678,7 +682,11 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
   } else {
     const unsigned lds_bias = lds_address(bias_s);
     const unsigned bias_delta = (unsigned)(reinterpret_cast<const char*>(p.bias) - reinterpret_cast<const char*>(p.wpk));
-    ly_seamless = (ABL & 1024) ? 0 : chain.seamless;      // diagnostic mask 1024: drained boundaries even where seamless ones are valid (A/B)
+    // Seamless boundaries are a property of what THIS workgroup owns, not of the launch: the tail workgroup of a batch
+    // that patches_per_wg does not divide may hold a single patch, and at F = 128 that is the case that must drain (its
+    // layer l+1 first item would stage what its own layer-l last item has not stored yet).  Uniform per workgroup.
+    // (diagnostic mask 1024: drained boundaries even where seamless ones are valid, A/B)
+    ly_seamless = (ABL & 1024) ? 0 : (chain.seamless != 0 && (my_imgs >= 2 || COUT == 256)) ? 1 : 0;
 #pragma unroll 1
     for (int l = 0; l < chain.n_layers; ++l) {
       // Layer-invariant values pass through an empty asm statement at the start of every layer (see their definition).

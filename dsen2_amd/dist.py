@@ -115,6 +115,35 @@ def gather_to_root(send, total, dst=0):
     return None
 
 
+def load_weights_on_root(path, cin, cout, num_layers, feature_size, device=None, src=0):
+    """C1 as the product path uses it (supres._get_model under an initialised process group): rank `src` alone opens and
+    parses the checkpoint (the stand-in for `model.load_weights(predict_file)`, testing/supres.py:63), every rank gets the
+    keras-flat float32 vector by ONE broadcast — the file (and h5py, for a keras .hdf5) is needed on rank `src` only.
+    A failure on the root is a failure everywhere: a one-element status goes first, so that no rank is left waiting in the
+    data broadcast; the root re-raises its own exception (OSError for a missing file, like keras), the others an OSError
+    naming the file and the root."""
+    from . import weights as _weights
+    rank, world = rank_world()
+    if world == 1:
+        return _weights.load_flat(path, cin, cout, num_layers, feature_size)
+    count = _weights.num_params(cin, cout, num_layers, feature_size)
+    backend = td.get_backend()
+    dev = torch.device('cpu') if backend != 'nccl' else (device or torch.device('cuda', torch.cuda.current_device()))
+    flat, err = None, None
+    if rank == src:
+        try:
+            flat = _weights.load_flat(path, cin, cout, num_layers, feature_size)
+        except Exception as e:          # reported to every rank below, then re-raised here
+            err = e
+    status = torch.tensor([0 if (rank == src and err is not None) else 1], dtype=torch.int64, device=dev)
+    td.broadcast(status, src=src)
+    if int(status.item()) == 0:
+        if err is not None:
+            raise err
+        raise OSError('rank %d could not read the weights (name = %r); see its error' % (src, path))
+    return broadcast_weights(flat, count, device=device, src=src)
+
+
 def broadcast_weights(flat, count, device=None, src=0):
     """C1: `flat` (float32 ndarray) is only read on rank `src`; returns the ndarray on every rank."""
     rank, world = rank_world()

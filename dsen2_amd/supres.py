@@ -47,12 +47,21 @@ def _get_model(input_shape, deep, run_60):
         num_layers, feature_size = 6, 128       # supres.py:59
     predict_file = _weight_file(deep, run_60)
     dev = _patches.default_device()
+    # (under torch.distributed the ranks' MDL_PATH may differ — only rank 0's is read — so every rank keys its cache on its
+    # own path string: all ranks hit or miss together as long as they make the same calls, which the collectives need anyway)
     key = (str(dev), tuple(s[0] for s in input_shape), num_layers, feature_size, os.path.abspath(predict_file), PRECISION)
     model = _MODEL_CACHE.get(key)
     if model is None:
         model = s2model(input_shape, num_layers=num_layers, feature_size=feature_size, device=dev, precision=PRECISION)
         print('Symbolic Model Created.')
-        model.load_weights(predict_file)
+        if _dist.rank_world()[1] > 1:
+            # one process per GPU: rank 0 alone reads the checkpoint, one RCCL broadcast delivers it (C1, dsen2_amd/dist.py)
+            # — the file need not exist on (and h5py need not be installed for) any other rank.  Collective: every rank
+            # gets here on its first call for this architecture, all of them make the same calls.
+            model.set_weights_flat(_dist.load_weights_on_root(predict_file, model.cin, model.cout, num_layers, feature_size,
+                                                              device=dev))
+        else:
+            model.load_weights(predict_file)
         _MODEL_CACHE[key] = model
     else:
         print('Symbolic Model Created.')

@@ -85,7 +85,15 @@ def _from_keras_hdf5(path, shapes):
         errors = [mismatch(o) for o in orders]
         if all(errors):
             raise ValueError('%s: %s' % (path, errors[0]))
-        for _, _, k, b in orders[errors.index(None)]:
+        chosen = orders[errors.index(None)]
+        if errors.index(None) == len(orders) - 1 and (len(orders) == 1 or errors[0] is not None):
+            # The fallback: the file's own layer_names order.  The shape chain cannot tell the 2d body layers (all F -> F)
+            # apart, so a file whose layer_names are not in creation order would load with permuted body weights — say
+            # which order was trusted instead of loading silently.
+            import warnings
+            warnings.warn('%s: conv layer names carry no usable numbering; trusting the file\'s layer_names order: %s'
+                          % (path, ', '.join(c[1] for c in chosen)), RuntimeWarning, stacklevel=3)
+        for _, _, k, b in chosen:
             parts += [k.astype(np.float32).ravel(), b.astype(np.float32)]
     return np.concatenate(parts)
 

@@ -12,7 +12,11 @@
  *     it; nothing synchronises unless stated.
  *   - every function returns DSEN2_OK (0) or a negative error code and never throws;
  *     dsen2_last_error() returns a thread-local description of the last failure.
- *   - the library uses the calling thread's current HIP device; one model handle per device.
+ *   - the library uses the calling thread's current HIP device; one model handle per device: a handle belongs to the
+ *     device that was current when it was created, and every call that takes a handle returns DSEN2_ERR_INVALID when the
+ *     calling thread's current device is another one (its weights live on the handle's device).
+ *   - no C++ exception crosses the ABI and no path of the library calls abort(): host-side failures (out of memory
+ *     included) come back as an error code.  (A fault raised by the GPU itself is the HIP runtime's to report.)
  *   - activations handed across the ABI are NCHW float32 (the reference runs keras in
  *     'channels_first', utils/DSen2Net.py:6); NHWC is internal.
  */
@@ -90,6 +94,18 @@ int dsen2_model_forward_timed(dsen2_model *m, const float *x10, const float *x20
                               int n, int h, int w, void *workspace, size_t workspace_bytes, void *stream, int iters,
                               float *body_ms_per_launch);
 
+/* Measurement hook (no reference counterpart): `warm` plain forward passes, then — without a synchronisation in between,
+ * so that the GPU never idles and is at its steady clock — `iters` forward passes exactly as dsen2_model_forward enqueues
+ * them, each with FOUR HIP events recorded on `stream`: before the first convolution, before the first and after the last
+ * residual-block convolution, after the output convolution.  ms5[0] = mean whole forward, ms5[1] = first convolution,
+ * ms5[2] = all residual-block convolutions together, ms5[3] = output convolution — consecutive intervals between the same
+ * time stamps, so ms5[1] + ms5[2] + ms5[3] = ms5[0]; ms5[4] = mean time per instrumented pass from the first pass's first
+ * event to the last pass's last event (what a pass costs WITH its event records and the gap to the next pass).
+ * bench.py's `roofline` object is built from these.  Synchronises the stream at the end. */
+int dsen2_model_forward_profile(dsen2_model *m, const float *x10, const float *x20, const float *x60, float *out,
+                                int n, int h, int w, void *workspace, size_t workspace_bytes, void *stream, int warm,
+                                int iters, float *ms5);
+
 /* ---- single-layer entry points (kernel-level parity tests and benchmarks) -------------------
  * One 3x3 'same' convolution (keras Conv2D as used at utils/DSen2Net.py:10,12,29,35) on NHWC
  * float32 device tensors.  host_kernel is HWIO (3,3,cin,cout), host_bias is [cout].
@@ -133,8 +149,9 @@ int dsen2_conv3x3_body_bf16(const void *dev_in_bf16, const float *host_kernel, c
 
 /* Body-convolution micro-benchmark hook: runs `iters` launches of the 128->128 (or F->F) kernel on
  * caller-provided NHWC buffers with already-packed weights held by `m` (layer index `layer`, 1-based
- * body conv number) and reports the mean kernel time in milliseconds measured with HIP events on
- * `stream`.  Used by bench.py for the roofline figure.
+ * body conv number), after 24 untimed launches of the same kernel (the chip's clock after an idle stretch), and reports the
+ * mean kernel time in milliseconds measured with HIP events on `stream`.  Used by bench.py (each epilogue alone on dense
+ * random operands, beside the in-network figure).
  * precision-1 models: dev_in is bf16 blocked; odd layers write bf16 blocked to dev_out; even (residual) layers take
  * dev_aux = one fp32-sized buffer holding the blocked hi tensor followed by the lo tensor and update it in place
  * (the last block's residual layer writes fp32 NHWC to dev_out instead). */

@@ -79,6 +79,55 @@ def test_broadcast_and_gather_to_root(world, total):
     assert res == {r: True for r in range(world)}
 
 
+def _c1_worker(rank, world, port, root_dir, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from dsen2_amd import dist, weights
+        # every rank has its OWN model directory (like supres.MDL_PATH on ranks with different working directories);
+        # only rank 0's holds the file
+        mine = os.path.join(root_dir, 'rank%d' % rank)
+        got = dist.load_weights_on_root(os.path.join(mine, 's2_032_lr_1e-04.hdf5'), 10, 6, 1, 128)
+        want = weights.random_he_uniform(10, 6, 1, 128, seed=21)
+        ok = got.dtype == np.float32 and np.array_equal(got, want)
+        # a checkpoint nobody has: the SAME failure on every rank (nobody left waiting in the broadcast), OSError like keras
+        try:
+            dist.load_weights_on_root(os.path.join(mine, 's2_030_lr_1e-05.hdf5'), 12, 2, 1, 128)
+            ok = False
+        except OSError as e:
+            ok = ok and ('s2_030' in str(e))
+        # ... and the group still works afterwards
+        t = torch.tensor([float(rank)])
+        td.all_reduce(t)
+        ok = ok and float(t.item()) == float(sum(range(world)))
+        q.put((rank, bool(ok)))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_only_rank_0_needs_the_checkpoint(world, tmp_path):
+    """C1 in the product path (supres._get_model -> dist.load_weights_on_root): rank 0 reads the file, the others receive
+    the flat vector by broadcast although THEIR model directory is empty; a missing file fails on all ranks alike."""
+    from dsen2_amd import weights
+    for r in range(world):
+        os.makedirs(str(tmp_path / ('rank%d' % r)))
+    np.save(str(tmp_path / 'rank0' / 's2_032_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 1, 128, seed=21))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c1_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res == {r: True for r in range(world)}
+
+
 def test_launch_environment_is_read_like_torch_distributed_run_sets_it(monkeypatch):
     """dist.launched_world(): RANK / LOCAL_RANK / WORLD_SIZE of a torch.distributed.run launch; a plain start is
     (0, 0, 1).  init_from_env() refuses an unknown backend before touching any device."""

@@ -15,7 +15,27 @@ HIPCC = build.HIPCC
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not available')
 def test_dma_kernels_asm_contract():
-    assert asm_contract.check_sources(HIPCC, build.FLAGS)
+    """... and the ISA hashes of the kernels whose PMC traffic bench.py quotes: kernel_isa.json (written by the build next
+    to the library it describes) must be what the sources compile to now, so a library built from other sources cannot
+    carry a current-looking hash."""
+    import json
+    hashes = asm_contract.check_sources(HIPCC, build.FLAGS)
+    assert set(hashes) == set(asm_contract.TRAFFIC_KERNELS)
+    if not build.needs_build():
+        assert json.load(open(asm_contract.ISA_JSON)) == hashes
+
+
+def test_traffic_figures_carry_the_hash_of_the_kernel_they_were_measured_on():
+    """profiles/body_conv_traffic.json: every entry that bench.py may quote names the ISA it was measured on (an entry
+    without a hash, or with another build's hash, is reported as stale by bench.py, never quoted)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'body_conv_traffic.json')
+    data = json.load(open(path))
+    assert 'dsen2_20_fp32' in data
+    for cfg, d in data.items():
+        assert cfg in asm_contract.TRAFFIC_KERNELS
+        if 'isa_sha256' in d:
+            assert len(d['isa_sha256']) == 64 and d['traffic_bytes'] >= d['algorithmic_bytes'] > 0
 
 
 GOOD = """
@@ -42,6 +62,36 @@ def test_checker_accepts_the_pattern_and_rejects_breakage():
         asm_contract.check_listing(GOOD.replace('\ts_nop 0\n', ''), 'x.hip')
     with pytest.raises(asm_contract.AsmContractError):       # M0 not saved
         asm_contract.check_listing(GOOD.replace('\ts_mov_b32 s5, m0\n', '').replace('\ts_mov_b32 m0, s5\n', ''), 'x.hip')
+
+
+CHAIN_GOOD = """
+_ZN5dsen228conv3x3_body16w_chain_kernelILi64ELi128ELi0EEEvNS_10ConvParamsENS_9ChainArgsE:
+	s_mov_b32 s5, m0
+	s_mov_b32 m0, s4
+	s_nop 0
+	buffer_load_dwordx4 v1, s[8:11], s2 offen lds
+	s_mov_b32 m0, s5
+	scratch_load_dword v0, off, off
+	s_waitcnt vmcnt(0)
+""" + "\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]\n" * 288 + """	s_waitcnt vmcnt(0)
+	s_endpgm
+"""
+
+
+def test_chain_kernel_scratch_accesses_must_sit_in_drained_regions():
+    """A spill outside the item bodies is a vector-memory operation the hand-counted waits do not know: allowed only
+    where the next vmcnt wait is vmcnt(0) (and before the next MFMA)."""
+    def kernel_rules(text):          # check_listing up to the per-kernel rules (the source-specific counts need the real file)
+        try:
+            asm_contract.check_listing(text, 'x.hip')
+        except asm_contract.AsmContractError as e:
+            return str(e)
+        return ''
+    assert kernel_rules(CHAIN_GOOD) == ''
+    bad = CHAIN_GOOD.replace('scratch_load_dword v0, off, off\n\ts_waitcnt vmcnt(0)', 'scratch_load_dword v0, off, off\n\ts_waitcnt vmcnt(3)')
+    assert 'scratch access outside a drained region' in kernel_rules(bad)
+    bad = CHAIN_GOOD.replace('scratch_load_dword v0, off, off\n\ts_waitcnt vmcnt(0)\n', 'scratch_load_dword v0, off, off\n')
+    assert 'scratch access outside a drained region' in kernel_rules(bad)
 
 
 OUT_GOOD = ''.join("""

@@ -17,9 +17,26 @@ def _rand(rng, shape, scale=1.0):
     return (rng.standard_normal(shape) * scale).astype(np.float32)
 
 
-# fp32 MFMA = k-ordered fmaf chain: error ~1e-7 * sum|a*b|.  K = 9*Cin products of O(1)*O(0.1).
-def _tol(cin):
-    return 2e-6 * np.sqrt(9 * cin)
+# Gates = 10 x what the kernels measure against the float64 oracle on these operands (inputs N(0,1), he-normal kernels:
+# outputs of rms ~1.4; `python -m pytest tests/test_gpu_conv.py -m gpu -s` prints every case's figures, and
+# profiles/r04_conv_gates.txt holds the run the numbers below were read from).  An fp32 MFMA chain over K = 9*Cin products
+# has rms error ~ 6e-8 * sqrt(K) * |a*b|, so the gate scales with sqrt(Cin); the residual epilogue scales the
+# convolution's error by res_scale = 0.1 and adds one rounding of the sum.  (Round 3 gated at 2e-6 * sqrt(9*Cin) = 6.8e-5 at
+# Cin 128: a systematic 1e-5 error would have passed.)
+# measured (profiles/r04_conv_gates.txt): relu 2.1e-7 / 5.9e-7 / 8.3e-7 at Cin 16 / 128 / 256; residual 8.7e-8 / 1.2e-7; output
+# convolution on the matrix cores 3.0e-7 / 4.2e-7 (nine partial sums of F products), on the vector units 8.3e-7 (one chain of 9F)
+RMS_GATE = {'relu': {16: 2e-6, 128: 5e-6, 256: 8e-6}, 'residual': {128: 9e-7, 256: 1.2e-6}, 'out': {128: 3e-6, 256: 4e-6},
+            'out_valu': {128: 8e-6}}
+MAX_GATE_FACTOR = 12          # max |error| <= 12 x the rms gate (a 5-sigma tail over <= 1e6 outputs is ~ 5 x the rms)
+
+
+def _check(y, ref, kind, cin, what=''):
+    e, mx = do.rmse(y, ref), float(np.abs(y - ref).max())
+    gate = RMS_GATE[kind][cin]
+    print('%-9s cin %3d %s: rmse %.3e (gate %.1e)  max %.3e (gate %.1e)  output rms %.3f'
+          % (kind, cin, what, e, gate, mx, MAX_GATE_FACTOR * gate, float(np.sqrt(np.mean(ref * ref)))))
+    assert e < gate, (kind, cin, what, e)
+    assert mx < MAX_GATE_FACTOR * gate, (kind, cin, what, mx)
 
 
 @pytest.mark.parametrize('cin,cout,n,h,w', [
@@ -39,8 +56,7 @@ def test_conv_relu_matches_oracle(cin, cout, n, h, w):
     from dsen2_amd.DSen2Net import conv3x3_nhwc
     y = conv3x3_nhwc(_nhwc(x), k, b, epilogue=0).cpu().numpy().transpose(0, 3, 1, 2)
     ref = c_oracle.conv3x3(x, k, b, relu=True)
-    assert np.abs(y - ref).max() < _tol(cin) * 4
-    assert do.rmse(y, ref) < _tol(cin)
+    _check(y, ref, 'relu', cin, '%dx%dx%d->%d' % (n, h, w, cout))
     assert (y >= 0).all()
 
 
@@ -54,7 +70,7 @@ def test_conv_residual_matches_oracle(feat, n, h, w):
     from dsen2_amd.DSen2Net import conv3x3_nhwc
     y = conv3x3_nhwc(_nhwc(x), k, b, epilogue=1, aux=_nhwc(res), res_scale=0.1).cpu().numpy().transpose(0, 3, 1, 2)
     ref = res.astype(np.float64) + 0.1 * c_oracle.conv3x3(x, k, b, relu=False)     # DSen2Net.py:12-15
-    assert do.rmse(y, ref) < _tol(feat)
+    _check(y, ref, 'residual', feat, '%dx%dx%d' % (n, h, w))
 
 
 def test_conv_residual_in_place():
@@ -69,7 +85,7 @@ def test_conv_residual_in_place():
               b.ctypes.data_as(_lib.c_float_p), ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(r.data_ptr()),
               1, 32, 32, 128, 128, 1, 0.1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     ref = res.astype(np.float64) + 0.1 * c_oracle.conv3x3(x, k, b)
-    assert do.rmse(r.cpu().numpy().transpose(0, 3, 1, 2), ref) < _tol(128)
+    _check(r.cpu().numpy().transpose(0, 3, 1, 2), ref, 'residual', 128, 'in place')
 
 
 @pytest.mark.parametrize('feat,cout,n,h,w', [(128, 6, 2, 32, 32), (128, 2, 1, 20, 35), (256, 6, 1, 16, 16)])
@@ -83,7 +99,7 @@ def test_conv_out_skip_nchw_matches_oracle(feat, cout, n, h, w):
     y = conv3x3_nhwc(_nhwc(x), k, b, epilogue=2, aux=torch.from_numpy(skip).cuda()).cpu().numpy()
     ref = c_oracle.conv3x3(x, k, b) + skip                                         # DSen2Net.py:35,38,41
     assert y.shape == (n, cout, h, w)
-    assert do.rmse(y, ref) < _tol(feat)
+    _check(y, ref, 'out', feat, '%dx%dx%d->%d' % (n, h, w, cout))
 
 
 # shapes of the tap-expanded matrix-core output kernel (conv3x3_out_mfma.hip): rows cut into 32-pixel blocks (edges at
@@ -104,8 +120,9 @@ def test_conv_out_shapes_match_oracle(feat, cout, n, h, w):
     y = conv3x3_nhwc(_nhwc(x), k, b, epilogue=2, aux=torch.from_numpy(skip).cuda()).cpu().numpy()
     ref = c_oracle.conv3x3(x, k, b) + skip
     assert y.shape == (n, cout, h, w)
-    assert do.rmse(y, ref) < _tol(feat)
-    assert np.abs(y - ref).max() < 40 * _tol(feat)          # no single pixel off (a block edge, a strip's first row)
+    # (Cout 7-8 and rows of Q too wide for LDS go to the vector-unit kernel: conv3x3_out.hip)
+    kind = 'out_valu' if cout > 6 or w > 224 else 'out'
+    _check(y, ref, kind, feat, '%dx%dx%d->%d' % (n, h, w, cout))      # incl. max: no single pixel off (a block edge, a strip's first row)
 
 
 @pytest.mark.parametrize('feat,cout,h,w', [(128, 6, 32, 32), (128, 6, 45, 100), (128, 2, 40, 192), (256, 6, 20, 64)])

@@ -131,6 +131,48 @@ def test_forward_timed_runs_the_same_forward():
     assert 0.0 < ms < 50.0
 
 
+def test_forward_profile_closes_on_itself():
+    """dsen2_model_forward_profile (what bench.py's roofline object is built from): the same output as
+    dsen2_model_forward; first + body + out = forward (consecutive intervals between the same four events); the host
+    clock per instrumented pass is not shorter than the events' forward."""
+    flat = do.he_uniform_weights(10, 6, 6, 128, seed=6, bias_scale=0.05)
+    xs = do.synthetic_inputs(64, 32, 32, (4, 6), seed=6)
+    m = _model((4, 6), 6, 128, flat)
+    dev = [torch.from_numpy(a).cuda() for a in xs]
+    y0 = m.forward_device(dev).clone()
+    y1 = torch.empty_like(y0)
+    p = m.profile_forward(dev, out=y1, iters=5)
+    assert torch.equal(y0, y1)
+    assert all(p[k] > 0 for k in ('forward_ms', 'first_ms', 'body_ms', 'out_ms', 'wall_ms')), p
+    assert abs(p['first_ms'] + p['body_ms'] + p['out_ms'] - p['forward_ms']) < 1e-3 * p['forward_ms'] + 2e-3, p
+    assert p['body_ms'] > p['first_ms'] and p['body_ms'] > p['out_ms'], p          # 12 of the 14 convolutions
+    assert p['wall_ms'] > 0.9 * p['forward_ms'], p
+
+
+def test_a_handle_belongs_to_the_device_it_was_created_on():
+    """include/dsen2_hip.h: one handle per device — a call with another current device returns DSEN2_ERR_INVALID instead
+    of handing device A's weights to kernels on device B.  (Needs two GPUs: skipped on a one-GPU box.)"""
+    import ctypes
+    from dsen2_amd import _lib
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one GPU visible: the mismatch cannot be produced')
+    flat = do.he_uniform_weights(10, 6, 1, 128, seed=6)
+    with torch.cuda.device(0):
+        m = _model((4, 6), 1, 128, flat)
+    xs = [torch.zeros((1, c, 16, 16), device='cuda:1') for c in (4, 6)]
+    out = torch.empty((1, 6, 16, 16), device='cuda:1')
+    ws = torch.empty(m.workspace_bytes(1, 16, 16), dtype=torch.uint8, device='cuda:1')
+    with torch.cuda.device(1):
+        rc = _lib.load().dsen2_model_forward(m._handle, xs[0].data_ptr(), xs[1].data_ptr(), None, out.data_ptr(), 1, 16, 16,
+                                             ws.data_ptr(), ws.numel(), None)
+        assert rc == _lib.ERR_INVALID and b'device' in _lib.load().dsen2_last_error()
+        assert _lib.load().dsen2_model_body_launches(m._handle, 1, 16, 16) == _lib.ERR_INVALID
+        f = np.zeros(m.count_params(), np.float32)
+        assert _lib.load().dsen2_model_load_weights(m._handle, f.ctypes.data_as(_lib.c_float_p), f.size) == _lib.ERR_INVALID
+    with torch.cuda.device(0):
+        assert m.body_launches(1, 16, 16) == 2
+
+
 @pytest.mark.parametrize('bands,feat', [((4, 6), 128), ((4, 6, 2), 128), ((4, 6), 256)])
 def test_first_layer_without_padding_mfmas_gives_the_same_bits(bands, feat):
     """The model's first convolution issues MFMAs for its 10 / 12 real input channels only; the single-layer entry

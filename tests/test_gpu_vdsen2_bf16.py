@@ -134,7 +134,14 @@ def test_dsen2_60_batch_512_properties():
     (256, 1, 256, 48, 40),      # 3 x 2 tiles per patch, ragged last column
     (128, 3, 256, 32, 32),      # F = 128, one patch per workgroup: DRAINED boundaries (a tile reads its neighbour's chunk 0)
     (128, 2, 512, 32, 32),      # F = 128, two patches per workgroup: seamless
-    (128, 2, 300, 16, 32),      # uneven: the last workgroups own one patch, the others two
+    (128, 2, 300, 16, 32),      # 150 workgroups of exactly two patches on a 256-CU card (fewer workgroups than CUs)
+    # odd n: patches_per_wg = 2 does not divide the batch, so the TAIL workgroup owns ONE patch and must drain at F = 128
+    # while every other workgroup runs seamless boundaries (decided per workgroup in the kernel; the compared sub-batch
+    # n-5 .. n-1 holds the tail workgroup's patch)
+    (128, 2, 301, 16, 32),      # one item per layer in the tail workgroup: it would read its own unwritten output
+    (128, 2, 401, 32, 32),      # two items per layer in the tail workgroup (tile 0 reads tile 1's halo row)
+    (128, 3, 257, 16, 16),      # single ragged tile per patch
+    (256, 1, 511, 32, 32),      # F = 256 tail workgroup with one patch: seamless stays valid (slab 1 = input chunks 4-7)
 ])
 def test_chain_kernel_equals_the_per_layer_kernels_bit_for_bit(feat, d, n, h, w):
     """precision 1: a batch that gives every CU whole patches runs its 2d body convolutions as ONE chain launch
@@ -147,6 +154,9 @@ def test_chain_kernel_equals_the_per_layer_kernels_bit_for_bit(feat, d, n, h, w)
     m = _model(BANDS20, d, feat, flat, 'bf16')
     dev = [torch.from_numpy(a).cuda() for a in xs]
     assert m.body_launches(n, h, w) == 1                      # the whole batch: one chain launch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if n % 2 == 1:
+        assert -(-n // cus) == 2, 'odd-n cases assume two patches per workgroup (256 CUs), got %d CUs' % cus
     if h * w > 16 * 32:
         assert m.body_launches(5, h, w) == 2 * d              # the sub-batch: layer by layer (several items per patch)
     y = m.forward_device(dev)

@@ -166,3 +166,25 @@ def test_whole_bundled_tiles(golden_dir, name):
     rec60 = quiet(po.recompose_images, q60, border=12, size=d[0].shape)
     np.testing.assert_allclose(rec60[1::5, 2::7], g['rec60_sub'], **TIGHT)
     np.testing.assert_allclose(rec60.astype(np.float64).sum(axis=0), g['rec60_cols'], rtol=1e-6)
+
+
+def test_a_patch_of_a_large_tile_is_a_patch_of_an_aligned_crop():
+    """The method tests/test_gpu_full_tile.py uses to check windows of a 10980^2 run without tiling 9801 patches on the CPU:
+    an aligned 336 x 336 crop of the tile has, in ITS patch grid, exactly the full grid's first / interior / clamped last
+    patch.  Shown here with the oracle's own tiling of a whole (smaller) tile whose size, like 10980 = 98 * 112 + 4, is not a
+    multiple of the stride."""
+    n = 112 * 9 + 100
+    rng = np.random.default_rng(0)
+    d10 = rng.integers(35, 13110, size=(n, n, 4)).astype(np.float32)
+    d20 = rng.integers(35, 13110, size=(n // 2, n // 2, 6)).astype(np.float32)
+    full10, full20 = po.get_test_patches(d10, d20, patchSize=128, border=8, interp=False)
+    per = n // 2 // 56 + 1                                   # used patches per axis (the clamped one included)
+    assert full10.shape[0] == per * per == 100
+
+    def crop(r0):
+        return po.get_test_patches(d10[r0:r0 + 336, r0:r0 + 336], d20[r0 // 2:(r0 + 336) // 2, r0 // 2:(r0 + 336) // 2],
+                                   patchSize=128, border=8, interp=False)
+    for r0, pick, idx in [(0, 0, 0), (3 * 112, 4, 4 * per + 4), (n - 336, 8, per * per - 1)]:
+        c10, c20 = crop(r0)
+        assert c10.shape[0] == 16
+        assert np.array_equal(c10[pick], full10[idx]) and np.array_equal(c20[pick], full20[idx]), (r0, pick, idx)

@@ -57,7 +57,9 @@ if args.lazy >= 0:
         return z
     d10, d20, d60 = _lazy(d10, 1), _lazy(d20, 2), _lazy(d60, 6)
 tmp = tempfile.mkdtemp()
-if args.deep:                       # testing/supres.py:55-57: VDSen2 reads s2_033 / s2_034
+if rank != 0:
+    pass        # the weight files exist in rank 0's directory ONLY: every other rank receives them by broadcast (C1, dist.load_weights_on_root)
+elif args.deep:                       # testing/supres.py:55-57: VDSen2 reads s2_033 / s2_034
     np.save(os.path.join(tmp, 's2_033_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 32, 256, seed=13))
     np.save(os.path.join(tmp, 's2_034_lr_1e-04.npy'), weights.random_he_uniform(12, 2, 32, 256, seed=14))
 else:

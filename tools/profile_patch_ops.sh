@@ -1,5 +1,11 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 kernel trace + PMC passes of the tiling / up-sampling / recomposition kernels.
+#   bash tools/profile_patch_ops.sh <tag>          -> gpurun_out/<tag>/{kernel_stats.md,pmc.md}
+# Every rocprofv3 invocation puts python3 itself after `--` and uses --pmc only together with --kernel-trace.
+set -u
+TAG=${1:?usage: tools/profile_patch_ops.sh <tag>}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r03_l_patch_pmc
+OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/bench_patch_ops.py > $OUT/trace.log 2>&1; echo "trace exit=$?"

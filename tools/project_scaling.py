@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Projection of the patch-sharded full tile (BASELINE configs[3]: DSen2_20 over 10980 x 10980, supres._run) for
+N = 1, 2, 4, 8 GPUs from stages MEASURED on one GPU — an expectation for the first hardware run to be compared with, NOT a
+scaling measurement (no N > 1 run on hardware exists).
+
+What a rank does in supres._run, and how each part scales:
+  1/N   host uint16 -> float32 of the row slab its patches read, H2D of the slab (measured here for rank 0's slab at each N:
+        the slabs overlap by the patches' borders, so it is slightly more than 1/N)
+  1/N   tiling, up-sampling, the network and the crop of the predictions into the send buffer for ceil(9801 / N) patches
+        (measured: the full run's GPU time / 9801 patches, and the time of rank 0's shard at each N)
+  C2    gather of the inner crops to rank 0: (N-1) peers x 2.95 GB / N each over their own xGMI link — not measurable on
+        one GPU; priced at 48 GB/s per link (a third of the 153 GB/s link peak: RCCL gather = point-to-point sends)
+  1     on rank 0 only: page-locked buffer for the 2.9 GB result (allocated under the GPU work: hidden while that work
+        is longer than the allocation), recomposition of all 9801 crops, D2H of the image
+Prints one JSON object; profiles/r04_scaling_projection.json is a committed run, DESIGN.md §6 quotes it.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dsen2_amd import dist as D, patches as P, supres, weights      # noqa: E402
+
+XGMI_GBPS = 48.0
+n = 10980
+rng = np.random.default_rng(0)
+d10 = rng.integers(35, 13110, size=(n, n, 4), dtype=np.uint16)
+d20 = rng.integers(35, 13110, size=(n // 2, n // 2, 6), dtype=np.uint16)
+tmp = tempfile.mkdtemp()
+np.save(os.path.join(tmp, 's2_032_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 6, 128, seed=11))
+supres.MDL_PATH = os.path.join(tmp, '')
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def T():
+    torch.cuda.synchronize()
+    return time.perf_counter()
+
+
+quiet(supres.DSen2_20, d10[:240, :240], d20[:120, :120])            # library load, model build, weight upload
+dev = P.default_device()
+model = quiet(supres._get_model, ((4, None, None), (6, None, None)), False, False)
+org, n_alloc = P.tile_origins(d20.shape, 64, 4)
+used = org.shape[0]
+patch, border, inner = 128, 8, 112
+out = {'tile': [n, n], 'patches': int(used), 'xgmi_gbps_assumed_per_link': XGMI_GBPS}
+
+# ---- the whole single-rank call (what N = 1 is) ----
+t0 = T(); y = quiet(supres.DSen2_20, d10, d20); t1 = T()
+out['n1_measured_s'] = round(t1 - t0, 3)
+del y
+
+# ---- rank 0's shard at each N: slab conversion + upload, GPU work on its patches, crop into the send buffer ----
+bs = model.batch_limit(patch, patch)
+per_n = {}
+for world in (1, 2, 4, 8):
+    per = D.per_rank(used, world)
+    my = org[:per]
+    r = {}
+    t0 = T()
+    imgs, orgs = [], []
+    for d, s, ps, b in ((d10, 2, 128, 8), (d20, 1, 64, 4)):
+        r0, r1 = supres._row_slab(my, s, ps, b, d.shape[0]) if world > 1 else (0, d.shape[0])
+        imgs.append(P._to_device_f32(d[r0:r1], dev))
+        sh = (my * s).astype(np.int32); sh[:, 0] -= r0
+        orgs.append(torch.from_numpy(np.ascontiguousarray(sh)).to(dev))
+    t1 = T()
+    r['slab_to_f32_and_h2d_s'] = round(t1 - t0, 4)
+    send = torch.empty((per, 6, inner, inner), dtype=torch.float32, device=dev)
+    t1 = T()
+    for i0 in range(0, per, bs):
+        nb = min(bs, per - i0)
+        p10 = P.gather_patches_device(imgs[0], my, 2, 8, 128, n_alloc, divisor=2000, first=i0, count=nb, origins_dev=orgs[0])
+        lr = P.gather_patches_device(imgs[1], my, 1, 4, 64, n_alloc, first=i0, count=nb, origins_dev=orgs[1])
+        p20 = P.interp_patches_device(lr, (patch, patch), post_divisor=2000)
+        yb = model.forward_device([p10, p20])
+        send[i0:i0 + nb].copy_(yb[:, :, border:patch - border, border:patch - border])
+    t2 = T()
+    r['gpu_shard_s'] = round(t2 - t1, 4)
+    r['patches_per_rank'] = int(per)
+    r['gather_in_s_at_assumed_link_rate'] = round((per * 6 * inner * inner * 4) / (XGMI_GBPS * 1e9), 4) if world > 1 else 0.0
+    per_n[world] = r
+    del imgs, orgs
+    if world < 8:
+        del send
+
+# ---- rank 0's serial tail: pinned allocation, recomposition of all crops, D2H ----
+crops = torch.empty((used, 6, inner, inner), dtype=torch.float32, device=dev)
+crops[:send.shape[0]] = send
+del send
+t0 = T(); host = torch.empty((n, n, 6), dtype=torch.float32, pin_memory=True); t1 = T()
+out['pinned_alloc_s'] = round(t1 - t0, 4)
+img = quiet(P.recompose_device, crops, 0, (n, n, 4), scale=2000); t2 = T()
+out['recompose_s'] = round(t2 - t1, 4)
+host.copy_(img, non_blocking=True); t3 = T()
+out['d2h_pinned_s'] = round(t3 - t2, 4)
+tail = out['recompose_s'] + out['d2h_pinned_s']
+proj = {}
+for world, r in per_n.items():
+    work = r['slab_to_f32_and_h2d_s'] + r['gpu_shard_s']
+    exposed_alloc = max(0.0, out['pinned_alloc_s'] - r['gpu_shard_s'])     # allocated while the GPU work runs
+    total = work + r['gather_in_s_at_assumed_link_rate'] + exposed_alloc + tail
+    proj[world] = {'projected_s': round(total, 3), 'per_rank_work_s': round(work, 3), 'rank0_tail_s': round(tail + exposed_alloc, 3),
+                   'gather_s': r['gather_in_s_at_assumed_link_rate'], **r}
+base = proj[1]['projected_s']
+for world in proj:
+    proj[world]['speedup_vs_projected_n1'] = round(base / proj[world]['projected_s'], 2)
+out['projection'] = proj
+print(json.dumps(out))
