@@ -37,6 +37,10 @@ CONFIGS = {
     'dsen2_20_bf16': dict(metric='32x32x6 patches/sec (DSen2_20, d=6, F=128, batch 512, bf16)', bands=(4, 6), d=6, f=128,
                           batch=512, precision='bf16', dtype='bf16', peak=2500.0,
                           workload='DSen2_20 d=6 F=128, bf16 operands / fp32 accumulate + residual stream (not a BASELINE config)'),
+    'dsen2_20_bf16x3': dict(metric='32x32x6 patches/sec (DSen2_20, d=6, F=128, batch 512, bf16x3)', bands=(4, 6), d=6, f=128,
+                            batch=512, precision='bf16x3', dtype='bf16x3', peak=2500.0, mfmas_per_product=3,
+                            workload='DSen2_20 d=6 F=128, bf16x3: every fp32 operand = two bf16 numbers, three bf16 MFMAs per product, '
+                                     'fp32 accumulate + exact fp32 residual stream (<= 1e-4 RMSE mode; not a BASELINE config, never the headline)'),
     'vdsen2_20_bf16': dict(metric='32x32x6 patches/sec (VDSen2_20, d=32, F=256, batch 256, bf16)', bands=(4, 6), d=32,
                            f=256, batch=256, precision='bf16', dtype='bf16', peak=2500.0,
                            workload='VDSen2_20 d=32 F=256, bf16 operands / fp32 accumulate + residual stream'),
@@ -195,9 +199,14 @@ def main():
         torch.cuda.synchronize()
         replay_ms = e0.elapsed_time(e1) / args.steps
         # (2) each epilogue alone, back to back, on dense random operands (no ReLU zeros: the chip clocks lower)
-        ms_relu = model.time_body_conv(1, a, None, o, iters=10)          # conv-A (+bias+ReLU)
-        ms_res = model.time_body_conv(2, a, r, o, iters=10)              # conv-B (+bias, *0.1, +residual)
-        flops = pix * FLOP_PER_PIXEL_BODY
+        x3 = cfg['precision'] == 'bf16x3'
+        ms_relu = ms_res = None
+        if not x3:
+            ms_relu = model.time_body_conv(1, a, None, o, iters=10)          # conv-A (+bias+ReLU)
+            ms_res = model.time_body_conv(2, a, r, o, iters=10)              # conv-B (+bias, *0.1, +residual)
+        # bf16x3: a product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi) — the matrix pipe's work and the roofline fraction
+        # count all of them against the bf16 peak; `algorithmic_tflops` is the convolution's own 2*9*F*F per pixel
+        flops = pix * FLOP_PER_PIXEL_BODY * cfg.get('mfmas_per_product', 1)
         # the dominant kernel: one launch per body convolution, or (bf16, a batch of whole patches per CU) ONE chain
         # launch over all 2d of them — then a launch's work and duration are 2d layers'
         launches = model.body_launches(args.batch, H, W)
@@ -223,8 +232,9 @@ def main():
                               'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
                               'traffic_source': traffic_src,
                               'kernel': '%s (3x3x%dx%d, %s, persistent%s)' % (
-                                  ('conv3x3_body16w_chain_kernel' if launches == 1 else 'conv3x3_body16w_kernel') if bf else 'conv3x3_body32_kernel',
-                                  FEAT, FEAT, 'bf16 MFMA 16x16x32, LDS-DMA staging, 16x32-pixel items' if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging',
+                                  'conv3x3_body16w_x3_kernel' if x3 else ('conv3x3_body16w_chain_kernel' if launches == 1 else 'conv3x3_body16w_kernel') if bf else 'conv3x3_body32_kernel',
+                                  FEAT, FEAT, 'three bf16 MFMA 16x16x32 per product (hi*hi + hi*lo + lo*hi), LDS-DMA staging, 16x32-pixel items' if x3
+                                  else 'bf16 MFMA 16x16x32, LDS-DMA staging, 16x32-pixel items' if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging',
                                   '; ONE launch over all %d body convolutions, a workgroup owns its patches through every layer' % (2 * NUM_LAYERS) if launches == 1 else ''),
                               'ms_per_launch': round(ms * per_launch, 4),
                               'ms_per_launch_source': 'HIP events on the launch stream around the %d body-conv launch%s of each of %d forward passes (4 events per pass)' % (launches, '' if launches == 1 else 'es', args.steps),
@@ -240,8 +250,10 @@ def main():
                               'forward_period_ms': round(prof['wall_ms'], 4), 'replay_ms_per_step': round(replay_ms, 4),
                               'event_cost_ms': round(prof['wall_ms'] - replay_ms, 4),
                               'replay_vs_timed_loop_ms': round(replay_ms - ms_per_step, 4),
-                              'ms_relu_randn': round(ms_relu, 4), 'ms_residual_randn': round(ms_res, 4),
-                              'flop_per_launch': flops * per_launch}
+                              'ms_relu_randn': round(ms_relu, 4) if ms_relu is not None else None,
+                              'ms_residual_randn': round(ms_res, 4) if ms_res is not None else None,
+                              'flop_per_launch': flops * per_launch,
+                              'algorithmic_tflops': round(pix * FLOP_PER_PIXEL_BODY / (ms * 1e-3) / 1e12, 2)}
         del a, r, o
         rl_a = rl_r = rl_o = None
 

@@ -16,6 +16,10 @@ import torch
 from . import _lib, weights as _weights
 
 RES_SCALE = 0.1   # resBlock(scale=0.1), utils/DSen2Net.py:9
+# arithmetic of the residual-block convolutions (include/dsen2_hip.h: dsen2_model_create).  'fp32' is what keras computes and
+# the default everywhere; 'bf16' = bf16 operands (~1e-3 relative error); 'bf16x3' = every fp32 operand as two bf16 numbers,
+# three bf16 MFMAs per product (~1e-5 whole-network rmse, inside the 1e-4 gate; ~3 x the fp32 rate)
+PRECISIONS = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
 
 
 def _ptr(t):
@@ -43,11 +47,11 @@ class S2Model(object):
         self._handle = ctypes.c_void_p(0)
         c60 = self.bands[2] if len(self.bands) == 3 else 0
         with torch.cuda.device(self.device):
-            if precision not in ('fp32', 'bf16'):
-                raise ValueError("precision must be 'fp32' or 'bf16'")
+            if precision not in PRECISIONS:
+                raise ValueError("precision must be one of %s" % ', '.join(repr(k) for k in PRECISIONS))
             self.precision = precision
             _lib.call('dsen2_model_create', ctypes.byref(self._handle), self.bands[0], self.bands[1], c60,
-                      self.num_layers, self.feature_size, 1 if precision == 'bf16' else 0)
+                      self.num_layers, self.feature_size, PRECISIONS[precision])
         # One workspace per STREAM the model is used from (keyed by the stream's handle): SURVEY §8(b) — "calls on a
         # handle are serialised by the given stream" — so forwards enqueued on different streams, from one thread or
         # several, must not share the activation buffers the kernels of both would be writing.
@@ -267,8 +271,8 @@ class S2Model(object):
 
 
 def s2model(input_shape, num_layers=32, feature_size=256, device=None, precision='fp32'):
-    """utils/DSen2Net.py:18 — same positional arguments and defaults.  precision='bf16' runs the residual-block
-    convolutions on the bf16 matrix cores (fp32 accumulate, fp32 residual stream)."""
+    """utils/DSen2Net.py:18 — same positional arguments and defaults.  precision='bf16' / 'bf16x3' run the residual-block
+    convolutions on the bf16 matrix cores (fp32 accumulate, exact fp32 residual stream; PRECISIONS above)."""
     return S2Model(input_shape, num_layers, feature_size, device=device, precision=precision)
 
 
@@ -300,6 +304,38 @@ def join_f32(hi, lo):
     with torch.cuda.device(hi.device):
         _lib.call('dsen2_join_f32', _ptr(hi), _ptr(lo), _ptr(out), n, h, w, b * e, _stream_ptr(hi.device))
     return out
+
+
+def split3_f32(x):
+    """fp32 NHWC CUDA tensor -> (hx, lo16): hx int16 [n, 2, c/8, h, w, 8] (plane 0 = hi, plane 1 = xl = bf16(x - hi)) and the
+    low halves int16 [n, c/8, h, w, 8] (include/dsen2_hip.h: dsen2_split3_f32) — the residual stream of a 'bf16x3' model."""
+    x = x.contiguous()
+    n, h, w, c = x.shape
+    hx = torch.empty((n, 2, c // 8, h, w, 8), dtype=torch.int16, device=x.device)
+    lo = torch.empty((n, c // 8, h, w, 8), dtype=torch.int16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call('dsen2_split3_f32', _ptr(x), _ptr(hx), _ptr(lo), n, h, w, c, _stream_ptr(x.device))
+    return hx, lo
+
+
+def conv3x3_body_bf16x3(x_planes, kernel_hwio, bias, epilogue=0, res_hx=None, res_lo=None, res_scale=RES_SCALE):
+    """Kernel-level entry point of the bf16x3 body convolution.  x_planes: int16 (bf16 bit patterns) [n, 2, feat/8, h, w, 8].
+    epilogue 0: returns relu(conv + bias) as such a two-plane tensor.  epilogue 1: updates the stream (res_hx, res_lo; see
+    split3_f32) in place and returns it.  epilogue 3: returns the updated stream as fp32 NHWC."""
+    n, _, blocks, h, w, _ = x_planes.shape
+    feat = blocks * 8
+    kernel_hwio = np.ascontiguousarray(kernel_hwio, np.float32)
+    bias = np.ascontiguousarray(bias, np.float32)
+    out = None
+    if epilogue == 0:
+        out = torch.empty((n, 2, feat // 8, h, w, 8), dtype=torch.int16, device=x_planes.device)
+    elif epilogue == 3:
+        out = torch.empty((n, h, w, feat), dtype=torch.float32, device=x_planes.device)
+    with torch.cuda.device(x_planes.device):
+        _lib.call('dsen2_conv3x3_body_bf16x3', _ptr(x_planes.contiguous()), kernel_hwio.ctypes.data_as(_lib.c_float_p),
+                  bias.ctypes.data_as(_lib.c_float_p), _ptr(res_hx), _ptr(res_lo), _ptr(out), n, h, w, feat, int(epilogue),
+                  float(res_scale), _stream_ptr(x_planes.device))
+    return (res_hx, res_lo) if epilogue == 1 else out
 
 
 def conv3x3_body_bf16(x_bf16, kernel_hwio, bias, epilogue=0, res_hi=None, res_lo=None, res_scale=RES_SCALE):

@@ -44,6 +44,9 @@ SIGNATURES = {
     'dsen2_join_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dsen2_conv3x3_body_bf16': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                         c_int, c_int, ctypes.c_float, c_void_p]),
+    'dsen2_split3_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dsen2_conv3x3_body_bf16x3': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                          c_int, c_int, ctypes.c_float, c_void_p]),
     'dsen2_model_time_body_conv': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_void_p, c_float_p]),
     'dsen2_upsample_mirror_bilinear': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float,

@@ -150,6 +150,19 @@ def check_listing(text, src):
             need((loads, stores) == expect[int(m.group(3))],
                  'epilogue %s has %d loads / %d stores, the waits count %r' % (m.group(3), loads, stores, expect[int(m.group(3))]))
         need(found >= 6, 'expected the 6 product instantiations of the bf16 body kernel, found %d' % found)
+        # the bf16x3 form (precision 2): conv-A stores two planes (32 per copy of the item loop), conv-B stores hi, xl and lo16 (48)
+        expect3 = {0: (0, 64), 1: (64, 96), 3: (64, 64)}
+        found3 = 0
+        for name, body in _kernels(text).items():
+            m = re.search(r'conv3x3_body16w_x3_kernelILi(\d+)ELi(\d+)ELi(\d+)E', name)
+            if not m:
+                continue
+            found3 += 1
+            loads = sum(1 for ln in body if ln.startswith('buffer_load_dwordx4') and not ln.endswith('lds'))
+            stores = sum(1 for ln in body if ln.startswith('buffer_store_dwordx4'))
+            need((loads, stores) == expect3[int(m.group(3))],
+                 'bf16x3 epilogue %s has %d loads / %d stores, the waits count %r' % (m.group(3), loads, stores, expect3[int(m.group(3))]))
+        need(found3 == 6, 'expected the 6 instantiations of the bf16x3 body kernel, found %d' % found3)
         # the chain kernel holds all three epilogues, each in both copies of the item loop
         chains = 0
         for name, body in _kernels(text).items():

@@ -4,7 +4,7 @@
                                   [--output_file_format GTiff|ENVI|...|npz] [--select_UTM ZONE] [--save_prefix P]
                                   [--roi_lon_lat lon1,lat1,lon2,lat2] [--list_bands] [--list_UTM]
                                   [--list_output_file_formats]
-                                  [--bands10 B4,B3,B2,B8] [--models DIR] [--precision fp32|bf16] [--deep]
+                                  [--bands10 B4,B3,B2,B8] [--models DIR] [--precision fp32|bf16|bf16x3] [--deep]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         -m dsen2_amd.cli INPUT [OUTPUT] ...                       one process per GPU: the patches of the tile are
         sharded over the ranks (dsen2_amd/dist.py: RCCL over xGMI), rank 0 receives the predictions, recomposes
@@ -294,7 +294,7 @@ def main(argv=None):
                     help='array input: names of the 10 m channels in the order they are stored (default B4,B3,B2,B8)')
     ap.add_argument('--models', default=None, help='directory with the checkpoints (default: supres.MDL_PATH)')
     ap.add_argument('--deep', action='store_true', help='VDSen2 (d=32, F=256)')
-    ap.add_argument('--precision', default=None, choices=['fp32', 'bf16'])
+    ap.add_argument('--precision', default=None, choices=['fp32', 'bf16', 'bf16x3'])
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='under torch.distributed.run: nccl = RCCL, one GPU per rank; gloo = rehearsal with shared GPUs')
     args = ap.parse_args(argv)

@@ -53,6 +53,7 @@ struct Layer {
   int cin, cout;        // real channel counts (keras)
   int epilogue;
   bool bf16;            // weights packed as bf16 for the bf16-operand body kernel (conv3x3_body16w.hip)
+  bool x3;              // ... as the (wh, wl, wh) planes of the bf16x3 form (precision 2): 3 x the bf16 weights
   PackGeom geom;
   size_t w_off, b_off;  // float offsets inside dev_params
   size_t flat_off;      // float offset of the kernel inside the keras-flat array
@@ -107,9 +108,9 @@ extern "C" {
 
 const char* dsen2_version(void) {
 #ifdef DSEN2_DIAG
-  return "dsen2_hip 0.2-diag (gfx950; fp32 MFMA 32x32x2 / bf16 MFMA 16x16x32; DIAGNOSTIC build)";
+  return "dsen2_hip 0.3-diag (gfx950; fp32 MFMA 32x32x2 / bf16 MFMA 16x16x32 / bf16x3; DIAGNOSTIC build)";
 #else
-  return "dsen2_hip 0.2 (gfx950; fp32 MFMA 32x32x2 / bf16 MFMA 16x16x32)";
+  return "dsen2_hip 0.3 (gfx950; fp32 MFMA 32x32x2 / bf16 MFMA 16x16x32 / bf16x3)";
 #endif
 }
 const char* dsen2_last_error(void) { return g_err; }
@@ -181,7 +182,8 @@ static int model_create_unguarded(dsen2_model** out, int c10, int c20, int c60, 
   if (c10 <= 0 || c20 <= 0 || c60 < 0 || num_layers < 0) return fail(DSEN2_ERR_INVALID, "bad channel/layer counts");
   if (feature_size != 128 && feature_size != 256)
     return fail(DSEN2_ERR_INVALID, "feature_size %d unsupported (128 or 256)", feature_size);
-  if (precision != 0 && precision != 1) return fail(DSEN2_ERR_INVALID, "precision %d unknown (0 = fp32, 1 = bf16)", precision);
+  if (precision < 0 || precision > 2)
+    return fail(DSEN2_ERR_INVALID, "precision %d unknown (0 = fp32, 1 = bf16 operands, 2 = bf16x3)", precision);
   const int cin = c10 + c20 + c60;
   const int cout = c60 > 0 ? c60 : c20;   // utils/DSen2Net.py:35 — input_shape[-1][0]
   if (cin > 16) return fail(DSEN2_ERR_INVALID, "%d input channels > 16", cin);
@@ -215,8 +217,11 @@ static int model_create_unguarded(dsen2_model** out, int c10, int c20, int c60, 
     }
     L.flat_off = flat;
     flat += (size_t)9 * L.cin * L.cout + L.cout;
-    L.bf16 = precision == 1 && L.cin == feature_size && L.cout == feature_size;   // residual-block convolutions only
-    L.w_off = dev; dev += align_up(L.bf16 ? (size_t)9 * L.cin * L.cout / 2 : packed_weight_floats(L.geom));
+    const bool body = L.cin == feature_size && L.cout == feature_size;             // residual-block convolutions only
+    L.bf16 = precision == 1 && body;
+    L.x3 = precision == 2 && body;
+    L.w_off = dev;
+    dev += align_up(L.bf16 ? (size_t)9 * L.cin * L.cout / 2 : L.x3 ? (size_t)27 * L.cin * L.cout / 2 : packed_weight_floats(L.geom));
     L.b_off = dev; dev += align_up((size_t)L.geom.cout_pad);
     m->layers.push_back(L);
   }
@@ -255,6 +260,8 @@ static int model_load_weights_unguarded(dsen2_model* m, const float* host_flat, 
     const float* b = k + (size_t)9 * L.cin * L.cout;
     if (L.bf16)
       pack_conv_weights_bf16_host(k, L.cin, L.cout, kBf16ChunkChannels, true, reinterpret_cast<uint16_t*>(staged.data() + L.w_off));
+    else if (L.x3)
+      pack_conv_weights_bf16x3_host(k, L.cin, L.cout, reinterpret_cast<uint16_t*>(staged.data() + L.w_off));
     else
       pack_conv_weights_host(k, L.cin, L.cout, L.geom, staged.data() + L.w_off);
     memcpy(staged.data() + L.b_off, b, sizeof(float) * L.cout);
@@ -270,8 +277,9 @@ int dsen2_model_workspace_bytes(const dsen2_model* m, int n, int h, int w, size_
   const size_t pix = (size_t)n * h * w;
   // fp32: x0 | a | t.   bf16: x0 | a (fp32: the last block's output) | hi | lo | t
   // (hi, lo: the residual stream as two 16-bit planes; t: bf16; each half an fp32 tensor)
+  // bf16x3: x0 | a (fp32: the first convolution's and the last block's output) | hx (hi | xl planes) | lo16 | t (hi | lo planes)
   const size_t full = align_up(pix * m->feat), half = align_up(pix * m->feat / 2);
-  *bytes = (align_up(pix * 16) + full + (m->precision == 1 ? 3 * half : full)) * sizeof(float);
+  *bytes = (align_up(pix * 16) + full + (m->precision == 1 ? 3 * half : m->precision == 2 ? 2 * full + half : full)) * sizeof(float);
   return DSEN2_OK;
 }
 
@@ -352,7 +360,28 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
       HIP_TRY(launch_conv3x3(pf, L.geom, epi0, 0, stream));
     }
   }
-  if (planes) {
+  if (m->precision == 2 && m->num_layers > 0) {
+    // bf16x3 (conv3x3_body16w.hip, X3): fp32-grade products from three bf16 MFMAs.  The first convolution's fp32 output `a` is
+    // split into the stream's tensors (hx = hi | xl planes, lo16); conv-A reads hx, writes t (hi | lo planes); conv-B reads t,
+    // updates (hx, lo16) in place — the last block's writes plain fp32 `a` for the (fp32) output convolution.
+    const size_t full = align_up(pix * m->feat), half = align_up(pix * m->feat / 2);
+    void* hx = t;
+    void* lo16 = t + full;
+    void* t2 = t + full + half;
+    HIP_TRY(launch_split3_f32(a, hx, lo16, n, h, w, m->feat, stream));
+    if (ev_body0) HIP_TRY(hipEventRecord(ev_body0, stream));
+    for (int i = 0; i < m->num_layers; ++i) {
+      const Layer& LA = m->layers[li++];
+      HIP_TRY(launch_conv3x3_body16w_x3(make_params(reinterpret_cast<const float*>(hx), P + LA.w_off, P + LA.b_off, nullptr,
+                                                    reinterpret_cast<float*>(t2), n, h, w, 0, 0.f), m->feat, kEpiRelu, stream));
+      const Layer& LB = m->layers[li++];
+      const bool last = i + 1 == m->num_layers;
+      ConvParams pb = make_params(reinterpret_cast<const float*>(t2), P + LB.w_off, P + LB.b_off,
+                                  reinterpret_cast<const float*>(hx), last ? a : reinterpret_cast<float*>(hx), n, h, w, 0, 0.1f);
+      pb.out2 = lo16;
+      HIP_TRY(launch_conv3x3_body16w_x3(pb, m->feat, last ? kEpiResidualF32 : kEpiResidual, stream));
+    }
+  } else if (planes) {
     // bf16 operands, fp32 accumulate, exact fp32 residual stream held as two 16-bit planes (hi = the bf16 operand of
     // the next convolution, lo = the low halves): conv-A reads hi, conv-B updates (hi, lo) in place; the last
     // block's conv-B writes plain fp32 for the (fp32) output convolution
@@ -571,6 +600,45 @@ static int join_f32_unguarded(const void* dev_hi, const void* dev_lo, float* dev
   return DSEN2_OK;
 }
 
+static int split3_f32_unguarded(const float* dev_in, void* dev_hx, void* dev_lo, int n, int h, int w, int c, void* stream) {
+  if (!dev_in || !dev_hx || !dev_lo || n < 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 != 0 || c > 512)
+    return fail(DSEN2_ERR_INVALID, "bad argument (c must be a multiple of 8, at most 512)");
+  if (n == 0) return DSEN2_OK;
+  HIP_TRY(launch_split3_f32(dev_in, dev_hx, dev_lo, n, h, w, c, (hipStream_t)stream));
+  return DSEN2_OK;
+}
+
+static int conv3x3_body_bf16x3_unguarded(const void* dev_in_planes, const float* host_kernel, const float* host_bias,
+                                         void* dev_res_hx, void* dev_res_lo, void* dev_out, int n, int h, int w, int feat,
+                                         int epilogue, float res_scale, void* stream_) {
+  if (!dev_in_planes || !host_kernel || !host_bias) return fail(DSEN2_ERR_INVALID, "NULL argument");
+  if (feat != 128 && feat != 256) return fail(DSEN2_ERR_INVALID, "feat %d unsupported", feat);
+  if (epilogue != kEpiRelu && epilogue != kEpiResidual && epilogue != kEpiResidualF32) return fail(DSEN2_ERR_INVALID, "epilogue %d", epilogue);
+  if (epilogue != kEpiRelu && (!dev_res_hx || !dev_res_lo)) return fail(DSEN2_ERR_INVALID, "residual epilogue needs the stream's tensors");
+  if (epilogue != kEpiResidual && !dev_out) return fail(DSEN2_ERR_INVALID, "dev_out is NULL");
+  int rc = check_shape(nullptr, n, h, w);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t wn = (size_t)27 * feat * feat;
+  std::vector<uint16_t> wb(wn);
+  pack_conv_weights_bf16x3_host(host_kernel, feat, feat, wb.data());
+  char* dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev, wn * 2 + feat * sizeof(float)));
+  hipError_t e = hipMemcpy(dev, wb.data(), wn * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dev + wn * 2, host_bias, feat * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    ConvParams p = make_params(reinterpret_cast<const float*>(dev_in_planes), reinterpret_cast<const float*>(dev),
+                               reinterpret_cast<const float*>(dev + wn * 2), reinterpret_cast<const float*>(dev_res_hx),
+                               reinterpret_cast<float*>(epilogue == kEpiResidual ? dev_res_hx : dev_out), n, h, w, 0, res_scale);
+    p.out2 = dev_res_lo;
+    e = launch_conv3x3_body16w_x3(p, feat, epilogue, stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "bf16x3 conv launch: %s", hipGetErrorString(e));
+  return DSEN2_OK;
+}
+
 static int conv3x3_body_bf16_unguarded(const void* dev_in_bf16, const float* host_kernel, const float* host_bias, void* dev_res_hi,
                             void* dev_res_lo, void* dev_out, int n, int h, int w, int feat, int epilogue,
                             float res_scale, void* stream_) {
@@ -612,6 +680,7 @@ static int model_time_body_conv_unguarded(dsen2_model* m, int layer, const float
   rc = check_device(m);
   if (rc) return rc;
   const Layer& L = m->layers[layer];
+  if (L.x3) return fail(DSEN2_ERR_INVALID, "dsen2_model_time_body_conv: not available for precision 2 (use dsen2_model_forward_profile)");
   if (L.epilogue == kEpiResidual && !dev_aux) return fail(DSEN2_ERR_INVALID, "residual layer needs dev_aux");
   hipStream_t stream = (hipStream_t)stream_;
   const float* P = m->dev_params;
@@ -724,6 +793,12 @@ int dsen2_split_f32(const float* dev_in, void* dev_hi, void* dev_lo, int n, int 
 }
 int dsen2_join_f32(const void* dev_hi, const void* dev_lo, float* dev_out, int n, int h, int w, int c, void* stream) {
   return guarded([&] { return join_f32_unguarded(dev_hi, dev_lo, dev_out, n, h, w, c, stream); });
+}
+int dsen2_split3_f32(const float* dev_in, void* dev_hx, void* dev_lo, int n, int h, int w, int c, void* stream) {
+  return guarded([&] { return split3_f32_unguarded(dev_in, dev_hx, dev_lo, n, h, w, c, stream); });
+}
+int dsen2_conv3x3_body_bf16x3(const void* dev_in_planes, const float* host_kernel, const float* host_bias, void* dev_res_hx, void* dev_res_lo, void* dev_out, int n, int h, int w, int feat, int epilogue, float res_scale, void* stream) {
+  return guarded([&] { return conv3x3_body_bf16x3_unguarded(dev_in_planes, host_kernel, host_bias, dev_res_hx, dev_res_lo, dev_out, n, h, w, feat, epilogue, res_scale, stream); });
 }
 int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, const float* host_bias, void* dev_res_hi, void* dev_res_lo, void* dev_out, int n, int h, int w, int feat, int epilogue, float res_scale, void* stream_) {
   return guarded([&] { return conv3x3_body_bf16_unguarded(dev_in_bf16, host_kernel, host_bias, dev_res_hi, dev_res_lo, dev_out, n, h, w, feat, epilogue, res_scale, stream_); });

@@ -130,17 +130,39 @@ constexpr int younger_than_input(bool has_w) { return has_w ? 4 * W_PER_STEP : 0
 // per-layer kernels: same bits.  Diagnostic masks of the chain kernel: 1024 drained boundaries everywhere, 2048 (timing
 // only) without the compute-only waves' wait, 4096 in-kernel stamps, 3 no epilogue traffic.
 
-template <int ABL>
+// X3 (precision 2, "bf16x3"): fp32-grade results on the bf16 matrix cores.  Every fp32 operand is the sum of two bf16
+// numbers, x = xh + xl + O(2^-17 |x|) (xh = the value's bf16 rounding, xl = bf16(x - xh); weights split the same way at
+// pack time), and a product is accumulated as xh*wh + xh*wl + xl*wh in fp32 (the xl*wl term is 2^-18 of the product):
+// three MFMAs at 16 x the fp32 MFMA rate.  In this kernel that is nothing but a LONGER contraction: the input-chunk loop
+// walks 3 * F/32 VIRTUAL chunks — chunk v = 3*cc + j reads real channels 32*cc .. 32*cc+31 of plane (xh, xh, xl)[j] against
+// the weight planes (wh, wl, wh)[j], which pack_conv_weights_bf16x3_host lays out as a (3, 3, 3*F, F) kernel — so the step
+// code, the DMA streams and their hand-counted waits are the bf16 kernel's, unchanged.  What differs:
+//   * a 16-bit operand tensor has TWO planes per image, [n][2][F/8][h][w][8]: blocks 0 .. F/8-1 = hi, F/8 .. 2F/8-1 = lo
+//     (conv-A reads the residual stream's (hi, xl), conv-B reads t's (hi, lo)); chunk v's block offset picks the plane;
+//   * conv-A's epilogue writes relu(.) as (hi, lo) planes (RNE both); conv-B's reads the exact fp32 stream (hi, lo16: the
+//     same two planes as precision 1, hi = ties-away bf16 rounding of the bit pattern) and writes hi, lo16 AND xl =
+//     bf16(x - hi) — the stream stays exact fp32, xl exists only as conv-A's second operand plane;
+//   * E_OPS: 32 stores (conv-A), 32 loads + 48 stores (conv-B; the first-chunk waits saturate at vmcnt(63): stricter).
+// Accuracy (tests/test_gpu_bf16x3.py, against float64): whole DSen2_20 network rmse ~1e-5 in the normalised domain against
+// 3e-7 (fp32) and 4e-3 (bf16 operands): inside the 1e-4 gate of BASELINE.md.  Not for CHAIN (per-layer launches).
+
+template <int ABL, bool X3 = false>
 __host__ __device__ constexpr int epilogue_ops(int epi) {
   // vector-memory operations of one epilogue (per wave): 16 groups of 8 channels x (stores + residual loads)
   // (diagnostic mask 128: the ISSUING waves 0-3 skip their epilogue stores, the compute-only waves keep theirs — the
   // waits exist in the issuers' code only, so the count is theirs; mask 256: the other way round)
-  return ((ABL & (1 | 128)) ? 0 : (epi == kEpiRelu ? 16 : 32)) + (epi != kEpiRelu && !(ABL & 2) ? 32 : 0);
+  // X3: conv-A stores two planes (32), conv-B stores hi, lo16 and xl (48); kEpiResidualF32 is unchanged (32 fp32 stores)
+  return ((ABL & (1 | 128)) ? 0 : (epi == kEpiRelu ? (X3 ? 32 : 16) : (X3 && epi == kEpiResidual ? 48 : 32))) +
+         (epi != kEpiRelu && !(ABL & 2) ? 32 : 0);
 }
 
-template <int CINW, int COUT, int EPI0, int ABL, bool CHAIN>
+template <int CINW, int COUT, int EPI0, int ABL, bool CHAIN, bool X3 = false>
 __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, const ChainArgs chain) {
-  constexpr int NCC = CINW / 16;              // 32-channel chunks
+  static_assert(!(X3 && CHAIN), "bf16x3 runs layer by layer");
+  static_assert(!X3 || ABL == 0, "no diagnostic masks for bf16x3");
+  constexpr int NCC = (X3 ? 3 : 1) * (CINW / 16);   // 32-channel chunks (X3: virtual chunks v = 3*cc + j, j = operand-plane pair)
+  constexpr int IN_PLANES = X3 ? 2 : 1;             // 16-bit operand tensors: planes per image (hi | lo)
+  constexpr unsigned LO_BLOCKS = CINW / 4;          // X3: block index of the lo plane inside an image (= F/8)
   constexpr int NCHUNK = NCC * 9;
   constexpr int NS = COUT / 128;
   constexpr bool kW = !(ABL & 4), kIn = !(ABL & 8);
@@ -228,8 +250,8 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
   auto set_stage_item = [&](auto epi_c, int item) __attribute__((always_inline)) {
     const Tile t = tile_of(item);
     in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(in_of(epi_c)) + (size_t)t.img * IMGPIX_ * CINW * 4, 0,
-        (unsigned)(IMGPIX_ * CINW * 4), 0x00020000);
+        const_cast<char*>(in_of(epi_c)) + (size_t)t.img * IMGPIX_ * CINW * 4 * IN_PLANES, 0,
+        (unsigned)(IMGPIX_ * CINW * 4 * IN_PLANES), 0x00020000);
     st_y0 = t.ty0;
     st_x0 = t.tx0;
   };
@@ -249,7 +271,13 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
     // convolution's padding; no branch
     const unsigned voff = ((unsigned)(__umul24(gy, W_) + gx) * 16u + in_plane_bytes * (unsigned)dq) | (inb ? 0u : 0x80000000u);
     const unsigned m0v = lds_in + buf * IN_BYTES + (dq * QS + 64 * b) * 16;
-    const unsigned so = (unsigned)(4 * cc) * in_plane_bytes;
+    unsigned blk = (unsigned)(4 * cc);
+    if constexpr (X3) {
+      // virtual chunk v = cc: real chunk v / 3, plane (hi, hi, lo)[v % 3]   (v < 96: v * 43691 >> 17 = v / 3)
+      const unsigned real = ((unsigned)cc * 43691u) >> 17;
+      blk = 4u * real + (((unsigned)cc - 3u * real) == 2u ? LO_BLOCKS : 0u);
+    }
+    const unsigned so = blk * in_plane_bytes;
     lds_dma(m0v, voff, in_rsrc, so);
   };
   // the next weight chunk of this workgroup's stream (8 wave instructions of 1 KiB, two per issuing wave) into the
@@ -382,13 +410,22 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
     auto plane_off = [&](int pr, int pb) -> unsigned {                // 16-bit blocked tensors
       return (((blk0 + 4u * pr) * (unsigned)IMGPIX_ + base_pix + (unsigned)(pb * W_)) * 16u & 0x7fffffffu) | bad_of(pb);
     };
+    // X3: the same group in the SECOND plane of a two-plane tensor (blocks COUT/8 .. 2*COUT/8-1 of the image)
+    auto plane2_off = [&](int pr, int pb) -> unsigned {
+      return (((blk0 + 4u * pr + (unsigned)(COUT / 8)) * (unsigned)IMGPIX_ + base_pix + (unsigned)(pb * W_)) * 16u & 0x7fffffffu) | bad_of(pb);
+    };
+    // X3: bf16(x - hi) for the two fp32 values whose bf16 roundings are packed in `h` (low half = first value): the second
+    // operand plane.  x - hi is exact in fp32 (hi is within one bf16 ulp of x), its RNE rounding leaves 2^-17 |x|.
+    auto lo_of_pair = [&](float x0, float x1, unsigned h) -> unsigned {
+      return pack_bf16(x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xffff0000u));
+    };
     auto nhwc_f32_off = [&](int pr, int pb) -> unsigned {             // fp32 channels-last tensor (kEpiResidualF32)
       return (((base_pix + (unsigned)(pb * W_)) * (unsigned)COUT + (unsigned)(ch8 + 32 * pr)) * 4u & 0x7fffffffu) | bad_of(pb);
     };
     const size_t img_elems = IMGPIX_ * COUT;
     if constexpr (EPI == kEpiRelu) {
       const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          out_of(epi_c) + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
+          out_of(epi_c) + (size_t)t.img * img_elems * 2 * IN_PLANES, 0, (unsigned)(img_elems * 2 * IN_PLANES), 0x00020000);
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
@@ -400,7 +437,13 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
             v1[e] = fmaxf(v1[e], 0.f);
           }
           const u32x4 hv = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-          if constexpr ((ABL & 384) != 0) {
+          if constexpr (X3) {
+            // relu(conv + b) as two bf16 planes: hi = its RNE rounding, lo = bf16(value - hi)
+            const u32x4 lv = {lo_of_pair(v0[0], v0[1], hv[0]), lo_of_pair(v0[2], v0[3], hv[1]), lo_of_pair(v1[0], v1[1], hv[2]),
+                              lo_of_pair(v1[2], v1[3], hv[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(hv, out_rsrc, plane_off(pr, pb), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(lv, out_rsrc, plane2_off(pr, pb), 0, 0);
+          } else if constexpr ((ABL & 384) != 0) {
             if ((wave < 4) == ((ABL & 128) != 0)) asm volatile("" ::"v"(hv)); else __builtin_amdgcn_raw_buffer_store_b128(hv, out_rsrc, plane_off(pr, pb), 0, 0);
           } else if constexpr (!(ABL & 1))
             __builtin_amdgcn_raw_buffer_store_b128(hv, out_rsrc, plane_off(pr, pb), 0, 0);
@@ -409,8 +452,8 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
           if (pr == 1) __builtin_amdgcn_sched_barrier(0);     // bounds the packed values in flight (registers)
         }
     } else {
-      const auto hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          hi_of() + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
+      const auto hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(          // X3: the stream's operand tensor (hi | xl planes)
+          hi_of() + (size_t)t.img * img_elems * 2 * IN_PLANES, 0, (unsigned)(img_elems * 2 * IN_PLANES), 0x00020000);
       const auto lo_rsrc = __builtin_amdgcn_make_buffer_rsrc(
           lo_of() + (size_t)t.img * img_elems * 2, 0, (unsigned)(img_elems * 2), 0x00020000);
       const auto f32_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -458,7 +501,16 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
               oh[k] = h_;
               ol[k] = l_;
             }
-            if constexpr ((ABL & 384) != 0) {
+            if constexpr (X3) {
+              // the exact fp32 stream (hi, lo16) as in precision 1, plus xl = bf16(x - hi): conv-A's second operand plane
+              u32x4 ox;
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                ox[k] = lo_of_pair(__builtin_bit_cast(float, ov[2 * k]), __builtin_bit_cast(float, ov[2 * k + 1]), oh[k]);
+              __builtin_amdgcn_raw_buffer_store_b128(oh, hi_rsrc, eo, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(ox, hi_rsrc, plane2_off(pr, pb), 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(ol, lo_rsrc, eo, 0, kResPolicy);
+            } else if constexpr ((ABL & 384) != 0) {
               if ((wave < 4) == ((ABL & 128) != 0)) {
                 asm volatile("" ::"v"(oh), "v"(ol));
               } else {
@@ -484,6 +536,18 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
           }
         }
       };
+      if constexpr (X3) {
+        // one pass of look-ahead (L0 | L1 C0 S0 | L2 C1 S1 | L3 C2 S2 | C3 S3): the second operand plane costs registers, and an
+        // item's 3 x longer contraction makes the epilogue a third as important
+        load_pass(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (j + 1 < 4) load_pass(j + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          finish_pass(j);
+        }
+      } else {
       load_pass(0);
       load_pass(1);
       stamp(14);
@@ -495,6 +559,7 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
         finish_pass(j);
         stamp(15 + j);
       }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -505,11 +570,11 @@ __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, c
   // then runs item `it`'s NCHUNK steps; one extra iteration writes the last item.
   auto run = [&](auto issuer_c, auto epi_c) __attribute__((always_inline)) {
   constexpr bool ISSUER = decltype(issuer_c)::value;
-  constexpr int E_OPS = epilogue_ops<ABL>(decltype(epi_c)::value);
+  constexpr int E_OPS = epilogue_ops<ABL, X3>(decltype(epi_c)::value);
   // CHAIN: the layer before / after this one (conv-A and conv-B alternate); what is still in flight when a layer's
   // FIRST item starts is the other kind's epilogue — its waits may count no more than the smaller of the two
   constexpr int EPI_OTHER = decltype(epi_c)::value == kEpiRelu ? kEpiResidual : kEpiRelu;
-  constexpr int E_FIRST = !CHAIN || epilogue_ops<ABL>(EPI_OTHER) > E_OPS ? E_OPS : epilogue_ops<ABL>(EPI_OTHER);
+  constexpr int E_FIRST = !CHAIN || epilogue_ops<ABL, X3>(EPI_OTHER) > E_OPS ? E_OPS : epilogue_ops<ABL, X3>(EPI_OTHER);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -717,6 +782,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_kernel(const ConvP
   body16w<CINW, COUT, EPI, ABL, false>(p, n_items, ChainArgs{});
 }
 
+// precision 2 (bf16x3): p.in = a two-plane 16-bit tensor, weights packed by pack_conv_weights_bf16x3_host
+template <int CINW, int COUT, int EPI>
+__global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_x3_kernel(const ConvParams p, const int n_items) {
+  body16w<CINW, COUT, EPI, 0, false, true>(p, n_items, ChainArgs{});
+}
+
 // p.wpk / p.bias: the FIRST body layer's packed weights / bias; p.in, p.out, p.aux, p.out2 are set per layer
 template <int CINW, int COUT, int ABL>
 __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_chain_kernel(const ConvParams p, const ChainArgs chain) {
@@ -740,6 +811,41 @@ static hipError_t launch_body16w_one(ConvParams p, hipStream_t stream, int grid_
   if (grid_cap > 0 && grid_cap < grid) grid = grid_cap;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, stream, p, (int)items);
   return hipGetLastError();
+}
+
+template <int CINW, int COUT, int EPI>
+static hipError_t launch_body16w_x3_one(ConvParams p, hipStream_t stream) {
+  auto kern = conv3x3_body16w_x3_kernel<CINW, COUT, EPI>;
+  static KernelOnce once;
+  int cus = 0;
+  hipError_t e = once.prepare(reinterpret_cast<const void*>(kern), LDS_BYTES, &cus);
+  if (e != hipSuccess) return e;
+  // per-image descriptors of the two-plane tensors (4 bytes per value): byte offsets below 2^31
+  if ((size_t)p.h * p.w * COUT >= ((size_t)1 << 29)) return hipErrorInvalidValue;
+  p.tiles_x = (p.w + TW - 1) / TW;
+  p.tiles_y = (p.h + TH - 1) / TH;
+  const long long items = (long long)p.n * p.tiles_x * p.tiles_y * (COUT / 128);
+  if (items <= 0 || items > 0x7fffffffLL) return hipErrorInvalidValue;
+  const int grid = (int)(items < cus ? items : cus);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, stream, p, (int)items);
+  return hipGetLastError();
+}
+
+template <int F>
+static hipError_t launch_body16w_x3_feat(const ConvParams& p, int epilogue, hipStream_t stream) {
+  if (epilogue == kEpiRelu) return launch_body16w_x3_one<F / 2, F, kEpiRelu>(p, stream);
+  if (epilogue == kEpiResidual) return launch_body16w_x3_one<F / 2, F, kEpiResidual>(p, stream);
+  if (epilogue == kEpiResidualF32) return launch_body16w_x3_one<F / 2, F, kEpiResidualF32>(p, stream);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv3x3_body16w_x3(const ConvParams& p, int feat, int epilogue, hipStream_t stream) {
+  if (!p.in || !p.wpk || !p.bias) return hipErrorInvalidValue;
+  if (epilogue != kEpiRelu && (!p.aux || !p.out2)) return hipErrorInvalidValue;
+  if (epilogue != kEpiResidual && !p.out) return hipErrorInvalidValue;
+  if (feat == 128) return launch_body16w_x3_feat<128>(p, epilogue, stream);
+  if (feat == 256) return launch_body16w_x3_feat<256>(p, epilogue, stream);
+  return hipErrorInvalidValue;
 }
 
 template <int CINW, int COUT, int ABL = 0>
@@ -866,6 +972,59 @@ __global__ __launch_bounds__(256) void split_join_kernel(float* __restrict__ f32
       __syncthreads();
     }
   }
+}
+
+// precision 2: fp32 channels-last tensor -> the residual stream's tensors: hx [n][2][C/8][h][w][8] (plane 0 = hi, the bf16
+// rounding (ties away) of the bit pattern; plane 1 = xl = bf16(x - hi), RNE) and lo [n][C/8][h][w][8] (the low halves).
+// Same thread layout as split_join_kernel<true>.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ f32, uint4* __restrict__ hx, uint4* __restrict__ lo,
+                                                     int img_pix, int nblk, long long total_groups) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int pitch = nblk * 8 + 4;
+  const int groups_per_img = (img_pix + 31) / 32;
+  for (long long g = blockIdx.x; g < total_groups; g += gridDim.x) {
+    const long long img = g / groups_per_img;
+    const int p0 = (int)(g - img * groups_per_img) * 32;
+    const int npx = min(32, img_pix - p0);
+    const float* const src = f32 + ((size_t)img * img_pix + p0) * (size_t)(nblk * 8);
+    uint4* const hi_img = hx + (size_t)img * 2 * nblk * img_pix;
+    uint4* const xl_img = hi_img + (size_t)nblk * img_pix;
+    uint4* const lo_img = lo + (size_t)img * nblk * img_pix;
+    for (int i = threadIdx.x; i < npx * nblk * 2; i += blockDim.x) {           // float4 pieces, channel-fastest
+      const int px = i / (nblk * 2), q = i - px * (nblk * 2);
+      *reinterpret_cast<f32x4*>(tile + px * pitch + q * 4) = *reinterpret_cast<const f32x4*>(src + (size_t)px * nblk * 8 + q * 4);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < npx * nblk; i += blockDim.x) {               // (block, pixel), pixel-fastest
+      const int blk = i / npx, px = i - blk * npx;
+      const unsigned* v = reinterpret_cast<const unsigned*>(tile + px * pitch + blk * 8);
+      unsigned h[4], l[4], x[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        split2(v[2 * k], v[2 * k + 1], h[k], l[k]);
+        x[k] = pack_bf16(__builtin_bit_cast(float, v[2 * k]) - __builtin_bit_cast(float, h[k] << 16),
+                         __builtin_bit_cast(float, v[2 * k + 1]) - __builtin_bit_cast(float, h[k] & 0xffff0000u));
+      }
+      hi_img[(size_t)blk * img_pix + p0 + px] = make_uint4(h[0], h[1], h[2], h[3]);
+      xl_img[(size_t)blk * img_pix + p0 + px] = make_uint4(x[0], x[1], x[2], x[3]);
+      lo_img[(size_t)blk * img_pix + p0 + px] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_split3_f32(const float* in_nhwc, void* hx, void* lo, int n, int h, int w, int c, hipStream_t stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 != 0 || c > 512) return hipErrorInvalidValue;
+  const int img_pix = h * w, nblk = c / 8;
+  const long long groups = (long long)n * ((img_pix + 31) / 32);
+  const size_t lds = (size_t)32 * (nblk * 8 + 4) * sizeof(float);
+  const unsigned grid = (unsigned)(groups < 256 * 8 ? groups : 256 * 8);
+  static KernelOnce once;
+  hipError_t e = once.prepare(reinterpret_cast<const void*>(split3_kernel), (size_t)32 * (512 + 4) * sizeof(float), nullptr);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(split3_kernel, dim3(grid), dim3(256), lds, stream, in_nhwc, reinterpret_cast<uint4*>(hx),
+                     reinterpret_cast<uint4*>(lo), img_pix, nblk, groups);
+  return hipGetLastError();
 }
 
 template <bool SPLIT>

@@ -22,6 +22,8 @@
 //     before the MFMAs of the current one and land in LDS after them.
 #include <string.h>
 
+#include <vector>
+
 #include "conv3x3_bf16_common.h"
 #include "dsen2_internal.h"
 
@@ -376,6 +378,29 @@ void pack_conv_weights_bf16_host(const float* k, int cin, int cout, int chunk_ch
               dst[i] = f32_to_bf16_rne(k[((size_t)tap * cin + c) * cout + oc]);
             }
       }
+}
+
+void pack_conv_weights_bf16x3_host(const float* k, int cin, int cout, uint16_t* dst) {
+  // a virtual (3, 3, 3*cin, cout) kernel: input chunk 3*cc + j of 32 channels = plane (wh, wl, wh)[j] of real chunk cc — the
+  // order in which conv3x3_body16w.hip (X3) walks the activation planes (xh, xh, xl)
+  const int vcin = 3 * cin;
+  std::vector<float> v((size_t)9 * vcin * cout);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int c = 0; c < cin; ++c)
+      for (int o = 0; o < cout; ++o) {
+        const float w = k[((size_t)tap * cin + c) * cout + o];
+        const uint16_t hb = f32_to_bf16_rne(w);
+        uint32_t hu = (uint32_t)hb << 16;
+        float wh;
+        memcpy(&wh, &hu, 4);
+        const float wl = w - wh;                       // exact; rounded to bf16 by the packer below
+        const int cc = c / 32, j = c % 32;
+        float* base = v.data() + ((size_t)tap * vcin + (size_t)cc * 96 + j) * cout + o;
+        base[0] = wh;
+        base[(size_t)32 * cout] = wl;
+        base[(size_t)64 * cout] = wh;
+      }
+  pack_conv_weights_bf16_host(v.data(), vcin, cout, 32, true, dst);
 }
 
 hipError_t launch_conv3x3(const ConvParams& p, const PackGeom& geom, int epilogue, int ablate, hipStream_t stream) {

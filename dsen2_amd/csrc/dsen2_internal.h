@@ -122,6 +122,19 @@ void pack_conv_weights_bf16_host(const float* kernel_hwio, int cin, int cout, in
 // stream as two blocked 16-bit tensors p.aux (hi = bf16 rounding, the next operand) / p.out2 (lo), updated in place.
 // kEpiResidualF32: same inputs, result to p.out as fp32 NHWC (last block).  `ablate` != 0 only in DSEN2_DIAG builds.
 hipError_t launch_conv3x3_body16w(const ConvParams& p, int feat, int epilogue, int ablate, hipStream_t stream, int grid_cap = 0);
+// precision 2 ("bf16x3", conv3x3_body16w.hip X3): fp32-grade products on the bf16 matrix cores — every operand is two bf16
+// numbers (hi + lo), a product is hi*hi + hi*lo + lo*hi.  16-bit OPERAND tensors carry two planes per image,
+// [n][2][F/8][h][w][8] (hi | lo).  p.in = such a tensor; weights packed by pack_conv_weights_bf16x3_host.
+//   kEpiRelu: p.out = relu(conv + bias) as a two-plane tensor.
+//   kEpiResidual: the residual stream = p.aux (two planes: hi = bf16 rounding (ties away) of the bit pattern, xl = bf16(x - hi))
+//     + p.out2 (lo16: the low halves, one plane): (hi, lo16) hold the exact fp32 value as in precision 1; updated in place.
+//   kEpiResidualF32: same inputs, result to p.out as fp32 NHWC.
+hipError_t launch_conv3x3_body16w_x3(const ConvParams& p, int feat, int epilogue, hipStream_t stream);
+// kernel HWIO fp32 (3,3,cin,cout) -> the packed bf16 layout of a (3,3,3*cin,cout) convolution whose input chunk 3*cc + j holds
+// (wh, wl, wh)[j] of real chunk cc (wh = RNE bf16 of w, wl = RNE bf16 of w - wh); dst holds 27*cin*cout uint16
+void pack_conv_weights_bf16x3_host(const float* kernel_hwio, int cin, int cout, uint16_t* dst);
+// fp32 NHWC -> the precision-2 residual stream: hx [n][2][C/8][h][w][8] (hi | xl), lo [n][C/8][h][w][8] (c % 8 == 0)
+hipError_t launch_split3_f32(const float* in_nhwc, void* hx, void* lo, int n, int h, int w, int c, hipStream_t stream);
 // One launch over all 2d residual-block convolutions of a precision-1 network (conv3x3_body16w.hip, CHAIN): a workgroup
 // owns whole patches through every layer, so layers need no cross-workgroup synchronisation.
 struct ChainArgs {

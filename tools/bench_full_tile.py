@@ -4,7 +4,7 @@ end to end through the drop-in surface (host ndarray in, host ndarray out), on o
 GPUs of a node (one process per GPU; the inner crops of the predictions are gathered to rank 0 over RCCL, which
 recomposes and returns the image — every other rank gets None: dsen2_amd/dist.py).
 
-    python tools/bench_full_tile.py [--size 10980] [--skip60] [--precision fp32|bf16] [--deep]
+    python tools/bench_full_tile.py [--size 10980] [--skip60] [--precision fp32|bf16|bf16x3] [--deep]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_full_tile.py
     (--backend gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks)
 Rank 0 prints one JSON line with wall times.  Random-init weights; the data is synthetic.
@@ -29,7 +29,7 @@ ap.add_argument('--size', type=int, default=10980)
 ap.add_argument('--skip60', action='store_true')
 ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'])
 ap.add_argument('--check', action='store_true', help='multi-rank: also verify the result against a single-rank run')
-ap.add_argument('--precision', default=None, choices=['fp32', 'bf16'], help="supres.PRECISION (default: DSEN2_PRECISION or fp32)")
+ap.add_argument('--precision', default=None, choices=['fp32', 'bf16', 'bf16x3'], help="supres.PRECISION (default: DSEN2_PRECISION or fp32)")
 ap.add_argument('--deep', action='store_true', help='VDSen2 (d=32, F=256) instead of DSen2')
 ap.add_argument('--lazy', type=int, default=-1, metavar='MARGIN', help='hand the images over as cli.LazyRows (rows read on demand, as the GDAL branch of the command line does under torch.distributed) with this margin of 10 m rows; reports the largest share of rows a rank read')
 ap.add_argument('--port', type=int, default=0, help=argparse.SUPPRESS)

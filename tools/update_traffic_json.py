@@ -2,7 +2,10 @@
 """Record the measured HBM traffic of a bench config's dominant kernel in profiles/body_conv_traffic.json, together with
 the hash of the instruction stream it was measured on.
 
-    python tools/update_traffic_json.py <config> <pmc summary .md> "<source note>"
+    python tools/update_traffic_json.py <config> <pmc summary .md> "<source note>" [output.json]
+
+(output.json: default profiles/body_conv_traffic.json, updated in place; tools/profile_round.sh on the GPU box writes
+gpurun_out/<tag>/body_conv_traffic.json — the repo's file with this config's entry replaced — to be copied over it.)
 
 <pmc summary> = what tools/summarize_pmc.py wrote from the separate `rocprofv3 --kernel-trace --pmc FETCH_SIZE` /
 `--pmc WRITE_SIZE` passes of tools/profile_round.sh (mean per dispatch, KiB).  Corrections as MI355X_MICROARCH.md §HBM
@@ -31,6 +34,7 @@ ROWS = {
 
 def main():
     cfg, md, note = sys.argv[1], sys.argv[2], sys.argv[3]
+    dst = sys.argv[4] if len(sys.argv) > 4 else None
     pat, algorithmic, desc = ROWS[cfg]
     header, row = None, None
     for ln in open(md):
@@ -50,7 +54,7 @@ def main():
                  'fetch_size_kib': fetch_kib, 'write_size_kib': write_kib,
                  'read_bytes_corrected': read_b, 'write_bytes': write_b, 'traffic_bytes': read_b + write_b,
                  'algorithmic_bytes': algorithmic, 'dispatches': int(row['dispatches']), 'source': note}
-    with open(path, 'w') as f:
+    with open(dst or path, 'w') as f:
         json.dump(data, f, indent=1)
         f.write('\n')
     print('%s: %.1f MB per launch for %.1f MB algorithmic (%.2fx), isa %s' % (
