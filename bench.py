@@ -41,6 +41,9 @@ CONFIGS = {
                             batch=512, precision='bf16x3', dtype='bf16x3', peak=2500.0, mfmas_per_product=3,
                             workload='DSen2_20 d=6 F=128, bf16x3: every fp32 operand = two bf16 numbers, three bf16 MFMAs per product, '
                                      'fp32 accumulate + exact fp32 residual stream (<= 1e-4 RMSE mode; not a BASELINE config, never the headline)'),
+    'vdsen2_20_bf16x3': dict(metric='32x32x6 patches/sec (VDSen2_20, d=32, F=256, batch 256, bf16x3)', bands=(4, 6), d=32, f=256,
+                             batch=256, precision='bf16x3', dtype='bf16x3', peak=2500.0, mfmas_per_product=3,
+                             workload='VDSen2_20 d=32 F=256, bf16x3 (three bf16 MFMAs per product, fp32 accumulate + exact fp32 residual stream)'),
     'vdsen2_20_bf16': dict(metric='32x32x6 patches/sec (VDSen2_20, d=32, F=256, batch 256, bf16)', bands=(4, 6), d=32,
                            f=256, batch=256, precision='bf16', dtype='bf16', peak=2500.0,
                            workload='VDSen2_20 d=32 F=256, bf16 operands / fp32 accumulate + residual stream'),
@@ -232,7 +235,7 @@ def main():
                               'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
                               'traffic_source': traffic_src,
                               'kernel': '%s (3x3x%dx%d, %s, persistent%s)' % (
-                                  'conv3x3_body16w_x3_kernel' if x3 else ('conv3x3_body16w_chain_kernel' if launches == 1 else 'conv3x3_body16w_kernel') if bf else 'conv3x3_body32_kernel',
+                                  ('conv3x3_body16w_x3_chain_kernel' if launches == 1 else 'conv3x3_body16w_x3_kernel') if x3 else ('conv3x3_body16w_chain_kernel' if launches == 1 else 'conv3x3_body16w_kernel') if bf else 'conv3x3_body32_kernel',
                                   FEAT, FEAT, 'three bf16 MFMA 16x16x32 per product (hi*hi + hi*lo + lo*hi), LDS-DMA staging, 16x32-pixel items' if x3
                                   else 'bf16 MFMA 16x16x32, LDS-DMA staging, 16x32-pixel items' if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging',
                                   '; ONE launch over all %d body convolutions, a workgroup owns its patches through every layer' % (2 * NUM_LAYERS) if launches == 1 else ''),

@@ -175,6 +175,16 @@ def check_listing(text, src):
             want = (sum(v[0] for v in expect.values()), sum(v[1] for v in expect.values()))
             need((loads, stores) == want, 'chain kernel has %d loads / %d stores in its epilogues, the waits count %r' % (loads, stores, want))
         need(chains == 2, 'expected the 2 product instantiations of the chain kernel, found %d' % chains)
+        chains3 = 0
+        for name, body in _kernels(text).items():
+            if not re.search(r'conv3x3_body16w_x3_chain_kernelILi(\d+)ELi(\d+)E', name):
+                continue
+            chains3 += 1
+            loads = sum(1 for ln in body if ln.startswith('buffer_load_dwordx4') and not ln.endswith('lds'))
+            stores = sum(1 for ln in body if ln.startswith('buffer_store_dwordx4'))
+            want = (sum(v[0] for v in expect3.values()), sum(v[1] for v in expect3.values()))
+            need((loads, stores) == want, 'bf16x3 chain kernel has %d loads / %d stores in its epilogues, the waits count %r' % (loads, stores, want))
+        need(chains3 == 2, 'expected the 2 instantiations of the bf16x3 chain kernel, found %d' % chains3)
 
 
 def check_out_mfma_listing(text, src='conv3x3_out_mfma.hip'):

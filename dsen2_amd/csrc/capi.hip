@@ -87,7 +87,7 @@ struct dsen2_model {
   Tuning tune;          // kernel structures, fixed at creation
   std::vector<Layer> layers;
   size_t n_params;
-  size_t chain_stride;  // precision 1: bytes between the packed weights (= between the biases) of consecutive body layers; 0 = not uniform
+  size_t chain_stride;  // precision 1 / 2: bytes between the packed weights (= between the biases) of consecutive body layers; 0 = not uniform
   size_t dev_param_floats;
   float* dev_params;
   bool loaded;
@@ -229,11 +229,11 @@ static int model_create_unguarded(dsen2_model** out, int c10, int c20, int c60, 
   m->dev_param_floats = dev;
   // the chain kernel (one launch over all body layers) addresses layer l's weights and bias at l * chain_stride
   m->chain_stride = 0;
-  if (precision == 1 && num_layers > 0) {
+  if ((precision == 1 || precision == 2) && num_layers > 0) {
     const size_t stride = m->layers[2].w_off - m->layers[1].w_off;
     bool uniform = true;
     for (int l = 1; l <= 2 * num_layers; ++l)
-      uniform = uniform && m->layers[l].bf16 && m->layers[l].w_off == m->layers[1].w_off + (size_t)(l - 1) * stride &&
+      uniform = uniform && (m->layers[l].bf16 || m->layers[l].x3) && m->layers[l].w_off == m->layers[1].w_off + (size_t)(l - 1) * stride &&
                 m->layers[l].b_off == m->layers[1].b_off + (size_t)(l - 1) * stride;
     if (uniform) m->chain_stride = stride * sizeof(float);
   }
@@ -332,15 +332,17 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
   const int abl = m->tune.ablate;
   size_t li = 0;
   const bool planes = m->precision == 1 && m->num_layers > 0;
+  const bool x3 = m->precision == 2 && m->num_layers > 0;
+  const size_t ws_full = align_up(pix * m->feat), ws_half = align_up(pix * m->feat / 2);
+  bool x3_stream_written = false;      // precision 2: the first convolution wrote the stream's tensors itself
   if (ev_fwd0) HIP_TRY(hipEventRecord(ev_fwd0, stream));
   {
     const Layer& L = m->layers[li++];            // DSen2Net.py:24-29: Concatenate + Conv2D + ReLU
     ConvParams pf = make_params(x0, P + L.w_off, P + L.b_off, nullptr, a, n, h, w, 0, 0.f);
     if (planes) {
       // a precision-1 model's first convolution writes the residual stream directly as its two blocked 16-bit planes
-      const size_t half = align_up(pix * m->feat / 2);
       pf.out = t;
-      pf.out2 = t + half;
+      pf.out2 = t + ws_half;
     }
     const int epi0 = planes ? (int)kEpiReluSplit : L.epilogue;
     // the default structure reads the NCHW inputs itself (conv3x3_first.hip); other channel counts, and the reference
@@ -350,10 +352,17 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
       ConvParams pd = pf;
       pd.in = x10;
       pd.aux = x20;
+      int epi_d = epi0;
+      if (x3) {            // precision 2: hx (hi | xl planes) and lo16 straight from the first convolution's epilogue
+        pd.out = t;
+        pd.out2 = t + ws_full;
+        epi_d = kEpiReluSplit3;
+      }
       const FirstInputs fi{x60, m->c10, m->c20, m->c60};
-      direct = launch_conv3x3_first(pd, fi, m->feat, epi0, stream, m->tune.first_ablate);
+      direct = launch_conv3x3_first(pd, fi, m->feat, epi_d, stream, m->tune.first_ablate);
       if (direct != hipSuccess && direct != hipErrorNotSupported)
         return fail(DSEN2_ERR_HIP, "first convolution launch: %s", hipGetErrorString(direct));
+      x3_stream_written = x3 && direct == hipSuccess;
     }
     if (direct != hipSuccess) {
       HIP_TRY(launch_pack_inputs(x10, x20, x60, m->c10, m->c20, m->c60, x0, n, h, w, stream));
@@ -361,16 +370,27 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
     }
   }
   if (m->precision == 2 && m->num_layers > 0) {
-    // bf16x3 (conv3x3_body16w.hip, X3): fp32-grade products from three bf16 MFMAs.  The first convolution's fp32 output `a` is
-    // split into the stream's tensors (hx = hi | xl planes, lo16); conv-A reads hx, writes t (hi | lo planes); conv-B reads t,
-    // updates (hx, lo16) in place — the last block's writes plain fp32 `a` for the (fp32) output convolution.
-    const size_t full = align_up(pix * m->feat), half = align_up(pix * m->feat / 2);
+    // bf16x3 (conv3x3_body16w.hip, X3): fp32-grade products from three bf16 MFMAs.  The first convolution writes the stream's
+    // tensors (hx = hi | xl planes, lo16) itself; conv-A reads hx, writes t (hi | lo planes); conv-B reads t, updates
+    // (hx, lo16) in place — the last block's writes plain fp32 `a` for the (fp32) output convolution.
     void* hx = t;
-    void* lo16 = t + full;
-    void* t2 = t + full + half;
-    HIP_TRY(launch_split3_f32(a, hx, lo16, n, h, w, m->feat, stream));
+    void* lo16 = t + ws_full;
+    void* t2 = t + ws_full + ws_half;
+    if (!x3_stream_written) HIP_TRY(launch_split3_f32(a, hx, lo16, n, h, w, m->feat, stream));   // (fallback first layer: fp32 `a`)
     if (ev_body0) HIP_TRY(hipEventRecord(ev_body0, stream));
-    for (int i = 0; i < m->num_layers; ++i) {
+    // one persistent launch over all 2d body convolutions when every CU gets whole patches (as for precision 1)
+    hipError_t chained = hipErrorNotSupported;
+    if (m->chain_stride != 0 && m->tune.chain && m->tune.grid_cap == 0 && m->tune.ablate == 0) {
+      const Layer& L1 = m->layers[li];
+      ConvParams pc = make_params(nullptr, P + L1.w_off, P + L1.b_off, nullptr, nullptr, n, h, w, 0, 0.1f);
+      ChainArgs ca;
+      ca.hi = hx; ca.lo = lo16; ca.t = t2; ca.out_f32 = a;
+      ca.layer_stride = (unsigned)m->chain_stride; ca.n_layers = 2 * m->num_layers; ca.patches_per_wg = 0; ca.seamless = 0;
+      chained = launch_conv3x3_body16w_chain(pc, ca, m->feat, stream, 0, true);
+      if (chained == hipSuccess) li += 2 * (size_t)m->num_layers;
+      else if (chained != hipErrorNotSupported) return fail(DSEN2_ERR_HIP, "bf16x3 chain kernel launch: %s", hipGetErrorString(chained));
+    }
+    for (int i = 0; i < m->num_layers && chained != hipSuccess; ++i) {
       const Layer& LA = m->layers[li++];
       HIP_TRY(launch_conv3x3_body16w_x3(make_params(reinterpret_cast<const float*>(hx), P + LA.w_off, P + LA.b_off, nullptr,
                                                     reinterpret_cast<float*>(t2), n, h, w, 0, 0.f), m->feat, kEpiRelu, stream));
@@ -450,7 +470,7 @@ static int model_body_launches_unguarded(const dsen2_model* m, int n, int h, int
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return fail(DSEN2_ERR_NO_DEVICE, "no HIP device");
-  const bool chain = m->precision == 1 && m->num_layers > 0 && m->chain_stride != 0 && m->tune.chain && m->tune.grid_cap == 0 &&
+  const bool chain = (m->precision == 1 || m->precision == 2) && m->num_layers > 0 && m->chain_stride != 0 && m->tune.chain && m->tune.grid_cap == 0 &&
                      body16w_chain_patches_per_wg(n, h, w, m->feat, cus) > 0;
   return chain ? 1 : 2 * m->num_layers;
 }

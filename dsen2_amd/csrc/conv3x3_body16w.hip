@@ -158,7 +158,6 @@ __host__ __device__ constexpr int epilogue_ops(int epi) {
 
 template <int CINW, int COUT, int EPI0, int ABL, bool CHAIN, bool X3 = false>
 __device__ __forceinline__ void body16w(const ConvParams p, const int n_items, const ChainArgs chain) {
-  static_assert(!(X3 && CHAIN), "bf16x3 runs layer by layer");
   static_assert(!X3 || ABL == 0, "no diagnostic masks for bf16x3");
   constexpr int NCC = (X3 ? 3 : 1) * (CINW / 16);   // 32-channel chunks (X3: virtual chunks v = 3*cc + j, j = operand-plane pair)
   constexpr int IN_PLANES = X3 ? 2 : 1;             // 16-bit operand tensors: planes per image (hi | lo)
@@ -793,6 +792,11 @@ template <int CINW, int COUT, int ABL>
 __global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_chain_kernel(const ConvParams p, const ChainArgs chain) {
   body16w<CINW, COUT, kEpiRelu, ABL, true>(p, 0, chain);
 }
+// ... of a precision-2 network: chain.hi = the stream's operand tensor (hi | xl planes), chain.t two planes as well
+template <int CINW, int COUT>
+__global__ __launch_bounds__(THREADS, 2) void conv3x3_body16w_x3_chain_kernel(const ConvParams p, const ChainArgs chain) {
+  body16w<CINW, COUT, kEpiRelu, 0, true, true>(p, 0, chain);
+}
 
 template <int CINW, int COUT, int EPI, int ABL = 0>
 static hipError_t launch_body16w_one(ConvParams p, hipStream_t stream, int grid_cap) {
@@ -848,9 +852,12 @@ hipError_t launch_conv3x3_body16w_x3(const ConvParams& p, int feat, int epilogue
   return hipErrorInvalidValue;
 }
 
-template <int CINW, int COUT, int ABL = 0>
+template <int CINW, int COUT, int ABL = 0, bool X3 = false>
 static hipError_t launch_body16w_chain_one(ConvParams p, ChainArgs c, hipStream_t stream) {
-  auto kern = conv3x3_body16w_chain_kernel<CINW, COUT, ABL>;
+  auto kern = [] {
+    if constexpr (X3) return conv3x3_body16w_x3_chain_kernel<CINW, COUT>;
+    else return conv3x3_body16w_chain_kernel<CINW, COUT, ABL>;
+  }();
   static KernelOnce once;
   int cus = 0;
   hipError_t e = once.prepare(reinterpret_cast<const void*>(kern), LDS_BYTES_CHAIN, &cus);
@@ -860,7 +867,7 @@ static hipError_t launch_body16w_chain_one(ConvParams p, ChainArgs c, hipStream_
   p.tiles_y = (p.h + TH - 1) / TH;
   // a layer = its packed weights, then (within layer_stride) its bias: the kernel addresses both through one descriptor
   const long long bias_delta = reinterpret_cast<const char*>(p.bias) - reinterpret_cast<const char*>(p.wpk);
-  if (bias_delta < (long long)(COUT / 128) * (CINW / 16) * 9 * WCH_BYTES || bias_delta + COUT * 4 > (long long)c.layer_stride)
+  if (bias_delta < (long long)(COUT / 128) * (X3 ? 3 : 1) * (CINW / 16) * 9 * WCH_BYTES || bias_delta + COUT * 4 > (long long)c.layer_stride)
     return hipErrorInvalidValue;
   c.patches_per_wg = body16w_chain_patches_per_wg(p.n, p.h, p.w, COUT, cus);
   if (c.n_layers <= 0) return hipErrorInvalidValue;
@@ -883,8 +890,14 @@ int body16w_chain_patches_per_wg(int n, int h, int w, int feat, int cus) {
   return ppw * ipp <= rounds_layerwise ? ppw : 0;
 }
 
-hipError_t launch_conv3x3_body16w_chain(const ConvParams& p, const ChainArgs& c, int feat, hipStream_t stream, int ablate) {
+hipError_t launch_conv3x3_body16w_chain(const ConvParams& p, const ChainArgs& c, int feat, hipStream_t stream, int ablate, bool x3) {
   if (!p.wpk || !p.bias || !c.hi || !c.lo || !c.t || !c.out_f32) return hipErrorInvalidValue;
+  if (x3) {
+    if (ablate != 0) return hipErrorInvalidValue;
+    if (feat == 128) return launch_body16w_chain_one<64, 128, 0, true>(p, c, stream);
+    if (feat == 256) return launch_body16w_chain_one<128, 256, 0, true>(p, c, stream);
+    return hipErrorInvalidValue;
+  }
 #ifdef DSEN2_DIAG
   if (ablate == 1024 && feat == 256) return launch_body16w_chain_one<128, 256, 1024>(p, c, stream);
   if (ablate == 1024 && feat == 128) return launch_body16w_chain_one<64, 128, 1024>(p, c, stream);

@@ -29,7 +29,8 @@ constexpr int kHaloPix = kHalo * kHalo;   // 324
 enum Epilogue : int {
   kEpiRelu = 0, kEpiResidual = 1, kEpiSkipNCHW = 2,
   kEpiResidualF32 = 3,   // bf16 body kernel only
-  kEpiReluSplit = 4      // first convolution of a precision-1 model: relu(conv + b) written as blocked (hi, lo) planes (out, out2)
+  kEpiReluSplit = 4,     // first convolution of a precision-1 model: relu(conv + b) written as blocked (hi, lo) planes (out, out2)
+  kEpiReluSplit3 = 5     // ... of a precision-2 model: out = the stream's operand tensor (two planes per image: hi | xl), out2 = lo16
 };
 
 struct ConvParams {
@@ -104,7 +105,8 @@ hipError_t launch_conv3x3_out_mfma(const ConvParams& p, int feat, hipStream_t st
 size_t out_mfma_weight_floats(int cin);
 void pack_out_mfma_weights_host(const float* kernel_hwio, int cin, int cout, float* dst);
 // First convolution reading the NCHW inputs directly (conv3x3_first.hip): p.in = x10, p.aux = x20; weights packed with
-// PackGeom{16, 128, 16, cout, .}; epilogue kEpiRelu (p.out fp32 NHWC) or kEpiReluSplit (p.out / p.out2 = (hi, lo) planes).
+// PackGeom{16, 128, 16, cout, .}; epilogue kEpiRelu (p.out fp32 NHWC), kEpiReluSplit (p.out / p.out2 = (hi, lo) planes) or
+// kEpiReluSplit3 (p.out = hi | xl planes, p.out2 = lo16: launch_split3_f32's tensors).
 // hipErrorNotSupported for channel counts other than 10 / 12 (then: launch_pack_inputs + launch_conv3x3).
 struct FirstInputs { const float* x60; int c10, c20, c60; };
 hipError_t launch_conv3x3_first(const ConvParams& p, const FirstInputs& f, int cout, int epilogue, hipStream_t stream, int ablate = 0);
@@ -149,7 +151,10 @@ struct ChainArgs {
 };
 // p.wpk / p.bias = the first body layer's packed weights / bias (the following layers' lie layer_stride bytes further
 // each); p.n, p.h, p.w, p.res_scale as usual; the tensors come from `c`.  c.patches_per_wg is filled in here.
-hipError_t launch_conv3x3_body16w_chain(const ConvParams& p, const ChainArgs& c, int feat, hipStream_t stream, int ablate = 0);
+// x3: the precision-2 form (c.hi = the stream's two-plane operand tensor hi | xl, c.t two planes, weights packed by
+// pack_conv_weights_bf16x3_host)
+hipError_t launch_conv3x3_body16w_chain(const ConvParams& p, const ChainArgs& c, int feat, hipStream_t stream, int ablate = 0,
+                                        bool x3 = false);
 // > 0: the chain kernel keeps every CU as busy as the per-layer launches do for this batch (that many patches per
 // workgroup); 0: use the per-layer kernels
 int body16w_chain_patches_per_wg(int n, int h, int w, int feat, int cus);

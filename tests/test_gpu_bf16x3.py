@@ -166,3 +166,63 @@ def test_bf16x3_dsen2_20_on_the_whole_bundled_tiles(golden_dir, tmp_path, monkey
     err = do.rmse(out.astype(np.float64) / 2000, ref)
     print('%s DSen2_20 bf16x3: normalised rmse %.3e' % (name, err))
     assert out.shape == (600, 600, 6) and err < RMSE_GATE and err < X3_EXPECTED
+
+
+@pytest.mark.parametrize('d,feat,n,h,w', [(2, 128, 2, 32, 32), (1, 256, 1, 21, 37), (3, 128, 1, 16, 33)])
+def test_precision2_forward_is_the_chain_of_its_kernel_level_operations(d, feat, n, h, w):
+    """dsen2_model_forward with precision 2 against the same network assembled from the kernel-level entry points (first
+    convolution in fp32 -> dsen2_split3_f32 -> bf16x3 conv-A / conv-B on the planes -> fp32 output convolution): bit for bit.
+    Pins what the forward fuses — the first convolution writing the stream's three planes itself (kEpiReluSplit3), the
+    in-place updates, the last block's fp32 form — to operations tested on their own."""
+    from dsen2_amd.DSen2Net import conv3x3_body_bf16x3, conv3x3_nhwc, s2model, split3_f32
+    flat = do.he_uniform_weights(10, 6, d, feat, seed=d + feat, bias_scale=0.05)
+    xs = do.synthetic_inputs(n, h, w, (4, 6), seed=3)
+    m = s2model(((4, None, None), (6, None, None)), num_layers=d, feature_size=feat, precision='bf16x3')
+    m.set_weights_flat(flat)
+    xd = [torch.from_numpy(a).cuda() for a in xs]
+    y = m.forward_device(xd)
+    layers = do.split_weights(np.asarray(flat), 10, 6, d, feat)
+    x0 = torch.zeros((n, h, w, 16), dtype=torch.float32, device='cuda')
+    x0[..., :4] = xd[0].permute(0, 2, 3, 1)
+    x0[..., 4:10] = xd[1].permute(0, 2, 3, 1)
+    k0 = np.zeros((3, 3, 16, feat), np.float32)
+    k0[:, :, :10] = layers[0][0]
+    a = conv3x3_nhwc(x0, k0, layers[0][1], epilogue=0)
+    hx, lo = split3_f32(a)
+    for i in range(d):
+        (ka, ba), (kb, bb) = layers[1 + 2 * i], layers[2 + 2 * i]
+        t = conv3x3_body_bf16x3(hx, ka, ba, epilogue=0)
+        if i + 1 < d:
+            conv3x3_body_bf16x3(t, kb, bb, epilogue=1, res_hx=hx, res_lo=lo, res_scale=0.1)
+        else:
+            a = conv3x3_body_bf16x3(t, kb, bb, epilogue=3, res_hx=hx, res_lo=lo, res_scale=0.1)
+    want = conv3x3_nhwc(a, layers[-1][0], layers[-1][1], epilogue=2, aux=xd[1].contiguous())
+    assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize('feat,d,n,h,w', [
+    (128, 2, 512, 32, 32),      # BASELINE configs[1]'s batch: two patches per workgroup, seamless boundaries
+    (128, 3, 256, 32, 32),      # one patch per workgroup at F = 128: drained boundaries
+    (128, 2, 401, 32, 32),      # odd batch: the tail workgroup owns one patch and drains, the others run seamless
+    (128, 2, 301, 16, 32),      # ... with a single item per layer in the tail workgroup
+    (256, 1, 256, 32, 32),      # F = 256, one patch per workgroup: seamless (slab 1 = virtual input chunks 12-23)
+    (256, 1, 256, 48, 40),      # 3 x 2 tiles per patch, ragged last column
+])
+def test_bf16x3_chain_kernel_equals_the_per_layer_kernels_bit_for_bit(feat, d, n, h, w):
+    """precision 2: a batch that gives every CU whole patches runs its 2d body convolutions as ONE chain launch
+    (conv3x3_body16w_x3_chain_kernel); a 5-patch sub-batch of the same inputs runs layer by layer (or, for single-tile
+    patches, as a drained chain).  Same arithmetic per item: the same bits, for every form of the layer boundary."""
+    flat = do.he_uniform_weights(10, 6, d, feat, seed=d + feat + n, bias_scale=0.05)
+    rng = np.random.Generator(np.random.PCG64(n + h))
+    xs = [rng.random((n, c, h, w), dtype=np.float32) * np.float32(5.0) for c in (4, 6)]
+    m = _model((4, 6), d, feat, flat)
+    dev = [torch.from_numpy(a).cuda() for a in xs]
+    assert m.body_launches(n, h, w) == 1
+    if h * w > 16 * 32:
+        assert m.body_launches(5, h, w) == 2 * d
+    y = m.forward_device(dev)
+    for first in (0, n // 2 - 2, n - 5):
+        sub = m.forward_device([t[first:first + 5].contiguous() for t in dev])
+        assert torch.equal(sub, y[first:first + 5]), (feat, d, n, h, w, first)
+    ref = c_oracle.forward([a[:2] for a in xs], flat, d, feat)
+    assert do.rmse(y[:2].cpu().numpy(), ref) < X3_EXPECTED
