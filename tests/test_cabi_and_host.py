@@ -178,3 +178,19 @@ def test_supres_constants_and_weight_file_selection():
     assert inspect.signature(patches.get_test_patches).parameters['border'].default == 4
     assert inspect.signature(patches.get_test_patches60).parameters['border'].default == 8
     assert list(inspect.signature(patches.recompose_images).parameters) == ['a', 'border', 'size']
+
+
+def test_overriding_the_product_library_is_never_silent(tmp_path):
+    """DSEN2_HIP_LIB exists for tools/ (A/B of experimental and diagnostic builds whose outputs can be wrong under ablation
+    masks): when it is set, _lib.load() says on stderr which file it loaded; without it, nothing is printed."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, 'dsen2_amd', 'libdsen2_hip.so')
+    code = 'from dsen2_amd import _lib; _lib.load(); print(_lib.LIB_PATH)'
+    env = dict(os.environ, DSEN2_HIP_LIB=lib)
+    p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert 'DSEN2_HIP_LIB overrides the product library' in p.stderr and lib in p.stderr
+    env.pop('DSEN2_HIP_LIB')
+    p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and 'overrides' not in p.stderr

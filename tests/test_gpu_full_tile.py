@@ -94,6 +94,38 @@ def test_dsen2_20_full_tile_identity_and_windows_vs_oracle(model_dir):
         assert err < RMSE_GATE_NORMALISED, which
 
 
+def test_dsen2_60_full_tile_identity_and_a_window_vs_oracle(tmp_path, monkeypatch):
+    """The other half of testing/s2_tiles_supres.py:332-342 at the real size: DSen2_60 over 10980^2 — 4356 patches of 192^2
+    (borders 12 / 6 / 2, 60 m stride 28, crops x 6 / x 3 / x 1: patches.py:83-156) — run-to-run identity and the interior
+    patch's 168 x 168 window against the oracle pipeline (same aligned-crop method: 504 x 504 = 3 x 3 patches)."""
+    from dsen2_amd import supres
+    flat = do.he_uniform_weights(12, 2, 6, 128, seed=42, bias_scale=0.02)
+    np.save(str(tmp_path / 's2_030_lr_1e-05.npy'), flat)
+    monkeypatch.setattr(supres, 'MDL_PATH', str(tmp_path) + os.sep)
+    supres.clear_model_cache()
+    rng = np.random.default_rng(2027)
+    d10 = rng.integers(35, 13110, size=(N, N, 4), dtype=np.uint16)
+    d20 = rng.integers(35, 13110, size=(N // 2, N // 2, 6), dtype=np.uint16)
+    d60 = rng.integers(35, 13110, size=(N // 6, N // 6, 2), dtype=np.uint16)
+    out = quiet(supres.DSen2_60, d10, d20, d60, deep=False)
+    assert out.shape == (N, N, 2) and out.dtype == np.float32 and np.isfinite(out[::61, ::67]).all()
+    assert np.array_equal(out, quiet(supres.DSen2_60, d10, d20, d60, deep=False))
+    supres.clear_model_cache()
+    inner, m = 192 - 24, 31
+    r0 = (m - 1) * inner
+    c = [d10[r0:r0 + 3 * inner, r0:r0 + 3 * inner].astype(np.float32),
+         d20[r0 // 2:(r0 + 3 * inner) // 2, r0 // 2:(r0 + 3 * inner) // 2].astype(np.float32),
+         d60[r0 // 6:(r0 + 3 * inner) // 6, r0 // 6:(r0 + 3 * inner) // 6].astype(np.float32)]
+    p = po.get_test_patches60(c[0], c[1], c[2], patchSize=192, border=12, f32_coords=True)
+    assert p[0].shape[0] == 16
+    pred = c_oracle.forward([a[4:5] / np.float32(2000) for a in p], flat, 6, 128)[0]
+    ref = pred[:, 12:180, 12:180].transpose(1, 2, 0).astype(np.float64)
+    y0 = m * inner
+    err = do.rmse(out[y0:y0 + inner, y0:y0 + inner].astype(np.float64) / 2000, ref)
+    print('10980^2 DSen2_60, interior patch window at (%d, %d): normalised rmse %.3e' % (y0, y0, err))
+    assert err < RMSE_GATE_NORMALISED
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))

@@ -29,6 +29,11 @@ ROWS = {
     'vdsen2_20_bf16': (r'conv3x3_body16w_chain_kernel<128, 256, 0>', 32 * (256 * 32 * 32 * 256 * (2 + 2) + 256 * 32 * 32 * 256 * (2 + 2 + 2 + 2 + 2)),
                        'conv3x3_body16w_chain_kernel<128,256,0>: ONE launch = all 64 body convolutions; per block hi read + t '
                        'written (conv-A), t + hi + lo read + hi + lo written (conv-B), x 32 blocks'),
+    # per value and block: conv-A reads hi + xl (4 B), writes t's hi + lo (4 B); conv-B reads t (4 B) and the stream's hi + lo16
+    # (4 B), writes hi, xl, lo16 (6 B) = 22 B; the last block writes fp32 (4 B) instead of the three planes: -2 B
+    'dsen2_20_bf16x3': (r'conv3x3_body16w_x3_chain_kernel<64, 128>', 512 * 32 * 32 * 128 * (6 * 22 - 2),
+                        'conv3x3_body16w_x3_chain_kernel<64,128>: ONE launch = all 12 body convolutions in bf16x3 (the second staging '
+                        'of the hi plane, 2 B per value and convolution, is not counted as algorithmic)'),
 }
 
 
