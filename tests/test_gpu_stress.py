@@ -29,10 +29,19 @@ def test_bf16_body_conv_matches_reference_structure_over_many_runs():
     assert 'total mismatching elements = 0' in p.stdout
 
 
+def test_bf16x3_body_conv_matches_reference_structure_over_many_runs():
+    """Same screen for the bf16x3 kernel against the fp32 reference structure on the fp32 operands, plus bit-exact consistency
+    of the stream's three planes."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stress_body_conv_bf16x3.py')], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert 'total mismatching elements = 0' in p.stdout
+
+
 def test_forward_is_bitwise_reproducible_across_launches():
     from dsen2_amd import weights as W
     from dsen2_amd.DSen2Net import s2model
-    for prec in ('fp32', 'bf16'):
+    for prec in ('fp32', 'bf16', 'bf16x3'):
         m = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128, precision=prec)
         m.set_weights_flat(W.random_he_uniform(10, 6, 6, 128, seed=5, bias_scale=0.05))
         xs = [torch.rand((300, 4, 32, 32), device='cuda') * 5, torch.rand((300, 6, 32, 32), device='cuda') * 5]
@@ -41,20 +50,21 @@ def test_forward_is_bitwise_reproducible_across_launches():
             assert torch.equal(m.forward_device(xs), ref), prec
 
 
-@pytest.mark.parametrize('feat,d,n', [(256, 8, 256), (128, 4, 256), (128, 4, 512)])
-def test_chain_kernel_over_many_launches_on_fresh_data(feat, d, n):
+@pytest.mark.parametrize('feat,d,n,prec', [(256, 8, 256, 'bf16'), (128, 4, 256, 'bf16'), (128, 4, 512, 'bf16'), (128, 4, 511, 'bf16'),
+                                           (128, 3, 512, 'bf16x3'), (128, 3, 511, 'bf16x3'), (256, 3, 256, 'bf16x3')])
+def test_chain_kernel_over_many_launches_on_fresh_data(feat, d, n, prec):
     """Race screen of the chain kernel's layer boundaries (seamless with one patch per workgroup at F = 256 and two at
     F = 128, drained at F = 128 with one): the chain launch depends on hand-placed waits for its OWN stores between
     layers, so a too-weak one shows up as a rare stale halo.  60 forwards on fresh random inputs each, every one
     compared bit for bit with the same patches run layer by layer (sub-batches of 5: the per-layer kernels)."""
     from dsen2_amd import weights as W
     from dsen2_amd.DSen2Net import s2model
-    m = s2model(((4, None, None), (6, None, None)), num_layers=d, feature_size=feat, precision='bf16')
+    m = s2model(((4, None, None), (6, None, None)), num_layers=d, feature_size=feat, precision=prec)
     m.set_weights_flat(W.random_he_uniform(10, 6, d, feat, seed=feat + d, bias_scale=0.05))
     assert m.body_launches(n, 32, 32) == 1 and m.body_launches(5, 32, 32) == 2 * d
     gen = torch.Generator(device='cuda').manual_seed(n + feat)
     bad = 0
-    for rep in range(60):
+    for rep in range(60 if prec == 'bf16' else 30):
         xs = [torch.rand((n, c, 32, 32), device='cuda', generator=gen) * 5 for c in (4, 6)]
         y = m.forward_device(xs)
         for first in (0, (37 * rep) % (n - 5), n - 5):
