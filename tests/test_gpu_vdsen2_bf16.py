@@ -4,7 +4,7 @@ utils/DSen2Net.py:31-32) with bf16 operands on the residual-block convolutions, 
 
 The reference computes in fp32, so the bf16 path has no bit-exact target: the float64 oracle on the SAME fp32
 weights is the yardstick and the gate is a stated fraction of the output's signal RMS.  The gate is justified by
-the error-vs-depth table this file prints (d = 4, 8, 16, 32; pasted into DESIGN.md §3.2b): 64 sequential
+the error-vs-depth table this file prints (d = 4, 8, 16, 32; pasted into HISTORY.md §3.2b): 64 sequential
 bf16-operand convolutions feed an fp32 residual stream through the 0.1 residual scale, so the error grows
 slowly with depth instead of compounding.
 """
@@ -60,7 +60,7 @@ def test_vdsen2_20_bf16_matches_oracle_at_full_depth(n, h, w):
 
 def test_bf16_error_vs_depth():
     """Error growth of the bf16 path with depth at F=256 (same inputs; each depth has its own he_uniform weights):
-    the table DESIGN.md §3.2b quotes.  Gate: every depth below BF16_GATE_REL, and d=32 at most 5x d=4 —
+    the table HISTORY.md §3.2b quotes.  Gate: every depth below BF16_GATE_REL, and d=32 at most 5x d=4 —
     the error must not compound with depth."""
     xs = do.synthetic_inputs(2, 16, 16, (4, 6), seed=5)
     rows = []
