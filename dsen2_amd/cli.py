@@ -42,13 +42,52 @@ BANDS60 = ['B1', 'B9']
 ARRAY_EXTENSIONS = ('.npz', '.mat')
 
 
-def _load(path):
+def _npz_member_memmap(path, name):
+    """Member `name` (.npy) of an UNCOMPRESSED .npz (what np.savez writes: ZIP_STORED) as a read-only np.memmap straight into the
+    zip file, or None when the member is deflated / not a plain array.  numpy's own np.load(..., mmap_mode) does not reach
+    into .npz files; a stored member is just a .npy file at a known offset."""
+    import struct
+    import zipfile
+    with zipfile.ZipFile(path) as zf:
+        try:
+            info = zf.getinfo(name + '.npy')
+        except KeyError:
+            return None
+        if info.compress_type != zipfile.ZIP_STORED:
+            return None
+    with open(path, 'rb') as f:
+        f.seek(info.header_offset)
+        local = f.read(30)                                   # local file header: signature .. extra-field length
+        if local[:4] != b'PK\x03\x04':
+            return None
+        name_len, extra_len = struct.unpack('<HH', local[26:30])
+        f.seek(info.header_offset + 30 + name_len + extra_len)
+        try:
+            major, minor = np.lib.format.read_magic(f)
+            shape, fortran, dtype = (np.lib.format.read_array_header_1_0(f) if (major, minor) == (1, 0)
+                                     else np.lib.format.read_array_header_2_0(f))
+        except Exception:
+            return None
+        if fortran or dtype.hasobject:
+            return None
+        return np.memmap(path, dtype=dtype, mode='r', offset=f.tell(), shape=shape, order='C')
+
+
+def _load(path, lazy=False):
+    """(data10, data20, data60) of an array file.  lazy=True (the command line under torch.distributed, one process per GPU):
+    members of an uncompressed .npz come back as read-only memory maps — DSen2_20 / DSen2_60 slice exactly the rows their
+    share of the patches needs (supres._run), so a rank pages in 1/world of the tile and the ranks of a node share ONE copy
+    in the page cache instead of holding the whole tile each; compressed members are read whole, as before."""
     ext = os.path.splitext(path)[1].lower()
     if ext == '.npz':
         z = np.load(path)
         def pick(*names):
             for n in names:
                 if n in z:
+                    if lazy:
+                        m = _npz_member_memmap(path, n)
+                        if m is not None:
+                            return m
                     return z[n]
             return None
         return pick('data10', 'd10'), pick('data20', 'd20'), pick('data60', 'd60')
@@ -342,7 +381,8 @@ def _run(args):
     product = None
     is_array = os.path.splitext(args.data_file)[1].lower() in ARRAY_EXTENSIONS
     if is_array:
-        data10, data20, data60 = _load(args.data_file)
+        from . import dist as _dist
+        data10, data20, data60 = _load(args.data_file, lazy=_dist.rank_world()[1] > 1)
         if data10 is None or data20 is None:
             print('No super-resolution performed, exiting')          # s2_tiles_supres.py:346-348
             return 0

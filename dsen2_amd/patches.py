@@ -40,6 +40,8 @@ def _to_device_f32(a, device):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=torch.float32).contiguous()
     a = np.ascontiguousarray(a)
+    if not a.flags.writeable:
+        a = np.array(a)           # a read-only memory map (cli._load under torch.distributed): copy the slab, not a view torch would warn about
     if a.dtype == np.uint16:
         t = torch.from_numpy(a.view(np.int16)).to(device)
         return (t.to(torch.int32) & 0xFFFF).to(torch.float32)

@@ -323,3 +323,39 @@ def test_gdal_branch_reads_rows_on_demand_under_torch_distributed(with_gdal, tmp
     assert cli.main(['S2A.zip', str(tmp_path / 'o.tif'), '--copy_original_bands']) == 0
     assert seen['types'] == ('LazyRows', 'LazyRows') and seen['rows'] == (56, 28)
     assert 'rank 0 read' in capsys.readouterr().err
+
+
+def test_array_file_is_memory_mapped_under_torch_distributed(fake_supres, tmp_path, monkeypatch):
+    """One process per GPU: the members of an uncompressed .npz reach DSen2_20 / DSen2_60 as read-only memory maps into the
+    zip file (a rank pages in only the rows it slices; the ranks of a node share one copy in the page cache), with the same
+    values and the same output as a single-process run; a compressed .npz is read whole, as before; so is any input of a
+    single-process run."""
+    from dsen2_amd import cli, dist, supres
+    d10, d20, d60 = _arrays(96)
+    inp, inc = str(tmp_path / 'tile.npz'), str(tmp_path / 'tile_c.npz')
+    np.savez(inp, data10=d10, data20=d20, data60=d60[:, :, :2])
+    np.savez_compressed(inc, data10=d10, data20=d20, data60=d60[:, :, :2])
+    for p, want in ((inp, 'memmap'), (inc, 'ndarray')):
+        a10, a20, a60 = cli._load(p, lazy=True)
+        assert (type(a10).__name__, type(a20).__name__, type(a60).__name__) == (want,) * 3
+        assert np.array_equal(a10, d10) and np.array_equal(a20, d20) and np.array_equal(a60, d60[:, :, :2])
+        assert a10.dtype == np.uint16 and np.array_equal(a10[17:40], d10[17:40])
+    assert type(cli._load(inp)[0]).__name__ == 'ndarray'
+    seen = {}
+    real20 = supres.DSen2_20
+
+    def spy20(a10, a20, deep=False):
+        seen['types'] = (type(a10).__name__, type(a20).__name__)
+        return real20(a10, a20, deep)
+    monkeypatch.setattr(supres, 'DSen2_20', spy20)
+    out1, out2 = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
+    assert cli.main([inp, out1, '--copy_original_bands', '--run_60']) == 0
+    assert seen['types'] == ('ndarray', 'ndarray')
+    monkeypatch.setattr(dist, 'rank_world', lambda: (0, 2))
+    assert cli.main([inp, out2, '--copy_original_bands', '--run_60', '--roi_x_y', '6,12,77,83']) == 0
+    assert seen['types'] == ('memmap', 'memmap')
+    monkeypatch.setattr(dist, 'rank_world', lambda: (0, 1))
+    out3 = str(tmp_path / 'three.npz')
+    assert cli.main([inp, out3, '--copy_original_bands', '--run_60', '--roi_x_y', '6,12,77,83']) == 0
+    b2, b3 = (np.load(o, allow_pickle=True)['bands'].item() for o in (out2, out3))
+    assert list(b2) == list(b3) and all(np.array_equal(b2[k], b3[k]) for k in b2)
