@@ -63,9 +63,10 @@ def _worker(rank, world, port, total, q):
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,total', [(2, 9), (2, 2), (2, 1), (3, 7), (3, 2)])
+@pytest.mark.parametrize('world,total', [(2, 9), (2, 2), (2, 1), (3, 7), (3, 2), (4, 9), (8, 13)])
 def test_broadcast_and_gather_to_root(world, total):
-    """(3, 7): uneven shards 3 + 3 + 1; (3, 2) and (2, 1): the last rank has no patch at all."""
+    """(3, 7): uneven shards 3 + 3 + 1; (3, 2) and (2, 1): the last rank has no patch at all; (8, 13): the node size the
+    north star names — six ranks with two patches, one with one, one with none."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
