@@ -45,6 +45,27 @@ def test_bench_single_gpu_line_has_contract_fields():
     assert 0 < r['roofline']['frac'] <= 1 and r['cpu_baseline']['kind'] == 'port'
 
 
+def test_bench_line_closes_on_itself_and_other_configs_run():
+    """The roofline object of the default line: launches x ms_per_launch + first_ms + out_ms = forward_ms (same events), the
+    traffic figure is quoted only with the ISA hash of this build; the bf16x3 config reports dtype "bf16x3" against the bf16
+    peak with three MFMAs per product and never claims the headline metric."""
+    def line(*extra):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline'] + list(extra),
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    r = line()
+    rl = r['roofline']
+    assert abs(rl['launches_per_forward'] * rl['ms_per_launch'] + rl['first_ms'] + rl['out_ms'] - rl['forward_ms']) < 2e-3
+    assert abs(rl['closure_ms'] - rl['forward_ms']) < 2e-3 and rl['replay_ms_per_step'] > 0
+    assert rl['traffic'] is None or 'STALE' not in rl['traffic_source']
+    assert (rl['traffic'] is None) == ('STALE' in rl['traffic_source'] or 'no committed' in rl['traffic_source'])
+    x = line('--config', 'dsen2_20_bf16x3')
+    assert x['dtype'] == 'bf16x3' and x['roofline']['peak'] == 2500.0 and 'bf16x3' in x['metric'] and x['metric'] != r['metric']
+    assert abs(x['roofline']['achieved'] / x['roofline']['algorithmic_tflops'] - 3.0) < 0.01
+    assert x['value'] > 1.5 * r['value']                      # the go / no-go threshold of the mode (measured: 3.0-3.1 x)
+
+
 def test_full_tile_two_ranks_gloo_matches_single_rank():
     """supres._run patch sharding + slab uploads + dist.gather_to_root with 2 ranks (gloo, both on the one GPU): the
     image rank 0 returns equals the single-rank image bit for bit; rank 1 returns None."""
