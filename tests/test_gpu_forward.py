@@ -196,7 +196,7 @@ def test_first_layer_without_padding_mfmas_gives_the_same_bits(bands, feat):
     assert torch.equal(y, y_ref)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 def test_one_model_on_two_streams_and_two_threads(precision):
     """calls on a handle are serialised by the stream they are given, so one model used from two streams
     (forwards enqueued alternately, nothing synchronised in between: their kernels interleave layer by layer) and from
