@@ -57,6 +57,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p]),
     'dsen2_recompose': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float,
                                 c_void_p]),
+    'dsen2_recompose_rows': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float,
+                                     c_int, c_int, c_void_p]),
 }
 
 _lib = None

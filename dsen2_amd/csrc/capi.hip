@@ -775,11 +775,22 @@ static int tile_gather_unguarded(const float* dev_img, int H, int W, int C, int 
   return DSEN2_OK;
 }
 
+static int recompose_rows_unguarded(const float* dev_patches, int count, int C, int P, int border, float* dev_img, int H, int W,
+                                    float scale, int row0, int row1, void* stream) {
+  if (!dev_patches || !dev_img || count <= 0 || C <= 0 || P <= 0 || border < 0 || H <= 0 || W <= 0)
+    return fail(DSEN2_ERR_INVALID, "bad argument");
+  hipError_t e = launch_recompose(dev_patches, count, C, P, border, dev_img, H, W, scale, row0, row1, (hipStream_t)stream);
+  if (e == hipErrorInvalidValue)
+    return fail(DSEN2_ERR_INVALID, "recompose geometry: count=%d P=%d border=%d H=%d W=%d rows [%d, %d)", count, P, border, H, W, row0, row1);
+  if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "recompose launch: %s", hipGetErrorString(e));
+  return DSEN2_OK;
+}
+
 static int recompose_unguarded(const float* dev_patches, int count, int C, int P, int border, float* dev_img, int H, int W,
                     float scale, void* stream) {
   if (!dev_patches || !dev_img || count <= 0 || C <= 0 || P <= 0 || border < 0 || H <= 0 || W <= 0)
     return fail(DSEN2_ERR_INVALID, "bad argument");
-  hipError_t e = launch_recompose(dev_patches, count, C, P, border, dev_img, H, W, scale, (hipStream_t)stream);
+  hipError_t e = launch_recompose(dev_patches, count, C, P, border, dev_img, H, W, scale, 0, H, (hipStream_t)stream);
   if (e == hipErrorInvalidValue)
     return fail(DSEN2_ERR_INVALID, "recompose geometry: count=%d P=%d border=%d H=%d W=%d", count, P, border, H, W);
   if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "recompose launch: %s", hipGetErrorString(e));
@@ -837,6 +848,9 @@ int dsen2_tile_gather(const float* dev_img, int H, int W, int C, int border, con
 }
 int dsen2_recompose(const float* dev_patches, int count, int C, int P, int border, float* dev_img, int H, int W, float scale, void* stream) {
   return guarded([&] { return recompose_unguarded(dev_patches, count, C, P, border, dev_img, H, W, scale, stream); });
+}
+int dsen2_recompose_rows(const float* dev_patches, int count, int C, int P, int border, float* dev_img, int H, int W, float scale, int row0, int row1, void* stream) {
+  return guarded([&] { return recompose_rows_unguarded(dev_patches, count, C, P, border, dev_img, H, W, scale, row0, row1, stream); });
 }
 int dsen2_model_body_launches(const dsen2_model* m, int n, int h, int w) {
   return guarded([&] { return model_body_launches_unguarded(m, n, h, w); });

@@ -176,7 +176,8 @@ hipError_t launch_upsample(const float* in, float* out, int planes, int h, int w
                            hipStream_t stream, bool general = false);
 hipError_t launch_tile_gather(const float* img, int H, int W, int C, int border, const int* origins, int count,
                               int P, float divisor, float* patches, hipStream_t stream);
+// rows [row0, row1) of the image (0, H = all of it)
 hipError_t launch_recompose(const float* patches, int count, int C, int P, int border, float* img, int H, int W,
-                            float scale, hipStream_t stream);
+                            float scale, int row0, int row1, hipStream_t stream);
 
 }  // namespace dsen2

@@ -348,11 +348,12 @@ hipError_t launch_tile_gather(const float* img, int H, int W, int C, int border,
 template <int C>
 __global__ __launch_bounds__(256) void recompose_kernel(const float* __restrict__ patches, int P, int border,
                                                         float* __restrict__ img, int H, int W, int x_tiles,
-                                                        int y_tiles, float scale, size_t total_pix, int c_rt) {
+                                                        int y_tiles, float scale, size_t first_pix, size_t total_pix, int c_rt) {
   const int inner = P - 2 * border;
   const int cc = C > 0 ? C : c_rt;
   const size_t pp = (size_t)P * P;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_pix; i += (size_t)gridDim.x * blockDim.x) {
+  // pixels [first_pix, total_pix) of the image: a band of rows (the whole image: first_pix = 0)
+  for (size_t i = first_pix + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_pix; i += (size_t)gridDim.x * blockDim.x) {
     const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
     // the LAST tile covering (y, x) wins, as in the reference's sequential overwrite
     const int ty = (y >= H - inner) ? y_tiles - 1 : y / inner;
@@ -371,18 +372,22 @@ __global__ __launch_bounds__(256) void recompose_kernel(const float* __restrict_
   }
 }
 
+// rows [row0, row1) of the image only (the whole image: 0, H).  The patches those rows read must have been written; the
+// others are not touched.
 hipError_t launch_recompose(const float* patches, int count, int C, int P, int border, float* img, int H, int W,
-                            float scale, hipStream_t stream) {
+                            float scale, int row0, int row1, hipStream_t stream) {
   const int inner = P - 2 * border;
   if (inner <= 0 || H < inner || W < inner) return hipErrorInvalidValue;
   const int x_tiles = (W + inner - 1) / inner, y_tiles = (H + inner - 1) / inner;
   if ((long long)x_tiles * y_tiles > count) return hipErrorInvalidValue;
-  const size_t total_pix = (size_t)H * W;
-  const dim3 grid(grid_for(total_pix, 256)), block(256);
+  if (row0 < 0 || row1 > H || row0 > row1) return hipErrorInvalidValue;
+  if (row0 == row1) return hipSuccess;
+  const size_t first_pix = (size_t)row0 * W, total_pix = (size_t)row1 * W;
+  const dim3 grid(grid_for(total_pix - first_pix, 256)), block(256);
   switch (C) {
-    case 2: hipLaunchKernelGGL(recompose_kernel<2>, grid, block, 0, stream, patches, P, border, img, H, W, x_tiles, y_tiles, scale, total_pix, C); break;
-    case 6: hipLaunchKernelGGL(recompose_kernel<6>, grid, block, 0, stream, patches, P, border, img, H, W, x_tiles, y_tiles, scale, total_pix, C); break;
-    default: hipLaunchKernelGGL(recompose_kernel<0>, grid, block, 0, stream, patches, P, border, img, H, W, x_tiles, y_tiles, scale, total_pix, C);
+    case 2: hipLaunchKernelGGL(recompose_kernel<2>, grid, block, 0, stream, patches, P, border, img, H, W, x_tiles, y_tiles, scale, first_pix, total_pix, C); break;
+    case 6: hipLaunchKernelGGL(recompose_kernel<6>, grid, block, 0, stream, patches, P, border, img, H, W, x_tiles, y_tiles, scale, first_pix, total_pix, C); break;
+    default: hipLaunchKernelGGL(recompose_kernel<0>, grid, block, 0, stream, patches, P, border, img, H, W, x_tiles, y_tiles, scale, first_pix, total_pix, C);
   }
   return hipGetLastError();
 }

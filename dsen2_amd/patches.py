@@ -189,6 +189,16 @@ def recompose_device(a_dev, border, size, scale=1.0):
     return img
 
 
+def recompose_rows_device(a_dev, border, img, row0, row1, scale=1.0):
+    """Rows [row0, row1) of `img` ([H,W,C] CUDA tensor) from the patch buffer a_dev [N,C,P,P] (dsen2_recompose_rows): only the
+    patches those rows read need to be final."""
+    n, c, p, _ = a_dev.shape
+    H, W = int(img.shape[0]), int(img.shape[1])
+    with torch.cuda.device(a_dev.device):
+        _lib.call('dsen2_recompose_rows', _ptr(a_dev), n, c, p, border, _ptr(img), H, W, float(scale), int(row0), int(row1),
+                  _stream(a_dev.device))
+
+
 def recompose_images(a, border, size=None):
     """utils/patches.py:374-405 — including the single-patch shortcut (:375-376) and the shape print (:392)."""
     if a.shape[0] == 1:

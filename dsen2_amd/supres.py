@@ -140,6 +140,16 @@ def _run(dsets, scales, patch, border, deep, run_60):
             shifted[:, 0] -= r0
             org_dev.append(torch.from_numpy(np.ascontiguousarray(shifted)).to(dev))      # uploaded once: the loop only enqueues
         bs = model.batch_limit(patch, patch)
+        # One rank, a large image: rows that are final are recomposed right after the batch that completes them — rows below
+        # min(t * inner, H - inner) once the first t tile rows of patches are done (the last `inner` rows belong to the clamped
+        # last tile row, patches.py:396-401) — and an event marks each band, so that the download can later run band by band
+        # on a copy stream UNDER the batches still computing (a D2H takes 5-40 % of its own time away from the kernels,
+        # profiles/r04_ablation.md §3).  This loop still only enqueues.
+        bands = None
+        if world == 1 and not single and _pinned_wanted((int(size[0]), int(size[1]), cout)) and \
+                os.environ.get('DSEN2_BANDED_OUTPUT', '1') != '0':
+            bands = dict(x_tiles=_patches.recompose_grid(size, patch, border)[0], rows=0, list=[],
+                         img=torch.empty((int(size[0]), int(size[1]), cout), dtype=torch.float32, device=dev))
         for i0 in range(0, count, bs):
             n = min(bs, count - i0)
             xs = []
@@ -158,6 +168,30 @@ def _run(dsets, scales, patch, border, deep, run_60):
             else:
                 y = model.forward_device(xs)
                 send[i0:i0 + n].copy_(y[:, :, border:patch - border, border:patch - border])
+            if bands is not None:
+                done = i0 + n
+                final = int(size[0]) if done == count else min((done // bands['x_tiles']) * inner, int(size[0]) - inner)
+                if final > bands['rows']:
+                    # `images *= SCALE` (supres.py:29) folded into the recomposition
+                    _patches.recompose_rows_device(pred_local, border, bands['img'], bands['rows'], final, scale=SCALE)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    bands['list'].append((bands['rows'], final, ev))
+                    bands['rows'] = final
+    if bands is not None and count > 0:
+        # everything is enqueued; the page-locked buffer is allocated now, under that work (as in the one-shot path below),
+        # and the bands whose events have fired by then start downloading at once
+        print((cout, size[0], size[1]))                                # patches.py:392
+        host = _host_output((int(size[0]), int(size[1]), cout))
+        if host is None:               # page-locked memory exhausted: the image is complete on the device
+            return bands['img'].cpu().numpy()
+        copy_stream = torch.cuda.Stream(dev)
+        with torch.cuda.stream(copy_stream):
+            for r0, r1, ev in bands['list']:
+                copy_stream.wait_event(ev)
+                host[r0:r1].copy_(bands['img'][r0:r1], non_blocking=True)
+        copy_stream.synchronize()
+        return host.numpy()            # ndarray view of the page-locked tensor (kept alive by the array)
     if single:
         if rank != 0:
             return None
@@ -190,9 +224,13 @@ def _run(dsets, scales, patch, border, deep, run_60):
 PINNED_OUTPUT_MIN_BYTES = 64 << 20     # DSEN2_PINNED_OUTPUT=0 disables; torch caches page-locked blocks for reuse
 
 
-def _host_output(shape):
+def _pinned_wanted(shape):
     nbytes = 4 * shape[0] * shape[1] * shape[2]
-    if os.environ.get('DSEN2_PINNED_OUTPUT', '1') == '0' or nbytes < PINNED_OUTPUT_MIN_BYTES:
+    return os.environ.get('DSEN2_PINNED_OUTPUT', '1') != '0' and nbytes >= PINNED_OUTPUT_MIN_BYTES
+
+
+def _host_output(shape):
+    if not _pinned_wanted(shape):
         return None
     try:
         return torch.empty(shape, dtype=torch.float32, pin_memory=True)

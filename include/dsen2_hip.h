@@ -211,6 +211,12 @@ int dsen2_tile_gather(const float *dev_img, int H, int W, int C, int border, con
  *   Requires count >= x_tiles*y_tiles, H >= inner, W >= inner. */
 int dsen2_recompose(const float *dev_patches, int count, int C, int P, int border, float *dev_img, int H,
                     int W, float scale, void *stream);
+/* The same for rows [row0, row1) of the image only: the rows a caller can finish (and start downloading) while later patches
+ * are still being computed.  Only the patches those rows read need to have been written — for rows below
+ * min(t * inner, H - inner), t = number of complete tile rows, those are the first t * x_tiles patches (the last
+ * `inner` rows belong to the clamped last tile row).  dev_patches / count describe the whole [count,C,P,P] buffer. */
+int dsen2_recompose_rows(const float *dev_patches, int count, int C, int P, int border, float *dev_img, int H,
+                         int W, float scale, int row0, int row1, void *stream);
 
 #ifdef __cplusplus
 }

@@ -228,3 +228,47 @@ def test_predict_deep_in_bf16(tmp_path, monkeypatch):
     print('VDSen2 bf16 through _predict: rmse / signal rms = %.3e' % rel)
     assert rel < BF16_GATE_REL
     supres.clear_model_cache()
+
+
+@pytest.mark.parametrize('shape,limit', [((600, 600), 5), ((570, 342), 7), ((240, 198), 1), ((1200, 348), 11)])
+def test_banded_output_equals_the_one_shot_output(model_dir, monkeypatch, shape, limit):
+    """supres._run on one rank recomposes the rows that are final after every batch (dsen2_recompose_rows) and downloads them
+    band by band on a copy stream under the batches still computing.  Forced here on small images (page-locked threshold 0,
+    a handful of patches per batch, so every band boundary and the clamped last tile row are exercised): the same bits and
+    prints as the one-shot path (DSEN2_BANDED_OUTPUT=0), for DSen2_20 and DSen2_60."""
+    from dsen2_amd import supres
+    from dsen2_amd.DSen2Net import S2Model
+    rng = np.random.default_rng(shape[0] + shape[1])
+    h, w = shape
+    d10 = rng.integers(35, 9000, size=(h, w, 4), dtype=np.uint16)
+    d20 = rng.integers(35, 9000, size=(h // 2, w // 2, 6), dtype=np.uint16)
+    d60 = rng.integers(35, 9000, size=(h // 6, w // 6, 2), dtype=np.uint16)
+    monkeypatch.setattr(supres, 'PINNED_OUTPUT_MIN_BYTES', 0)
+    monkeypatch.setattr(S2Model, 'batch_limit', lambda self, hh, ww: limit)
+    for fn, args in ((supres.DSen2_20, (d10, d20)), (supres.DSen2_60, (d10, d20, d60))):
+        monkeypatch.setenv('DSEN2_BANDED_OUTPUT', '1')
+        a, pa = quiet(fn, *args, deep=False)
+        monkeypatch.setenv('DSEN2_BANDED_OUTPUT', '0')
+        b, pb = quiet(fn, *args, deep=False)
+        assert a.shape == b.shape == (h, w, a.shape[2]) and a.dtype == np.float32
+        assert np.array_equal(a, b), (fn.__name__, shape, limit)
+        assert pa == pb
+
+
+def test_recompose_rows_is_the_full_recomposition_cut_into_bands():
+    """dsen2_recompose_rows over any partition of the rows = dsen2_recompose, bit for bit; rows outside the band are not
+    touched; a bad range is refused."""
+    import torch
+    from dsen2_amd import _lib, patches as gp
+    rng = np.random.default_rng(5)
+    a = torch.from_numpy(rng.standard_normal((12, 6, 32, 32)).astype(np.float32)).cuda()     # 4 x 3 tiles of inner 24
+    size = (80, 60)
+    full = gp.recompose_device(a, 4, size, scale=2000.0)
+    img = torch.full((80, 60, 6), -7.0, device='cuda')
+    for r0, r1 in ((0, 1), (1, 24), (24, 55), (55, 56), (56, 80)):
+        gp.recompose_rows_device(a, 4, img, r0, r1, scale=2000.0)
+        assert torch.equal(img[:r1], full[:r1]) and bool((img[r1:] == -7.0).all())
+    with pytest.raises(_lib.DSen2Error):
+        gp.recompose_rows_device(a, 4, img, 10, 81)
+    with pytest.raises(_lib.DSen2Error):
+        gp.recompose_rows_device(a, 4, img, 30, 20)
