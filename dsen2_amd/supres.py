@@ -129,6 +129,7 @@ def _run(dsets, scales, patch, border, deep, run_60):
     else:
         send = torch.empty((per, cout, inner, inner), dtype=torch.float32, device=dev)
         pred_local = None
+    bands = None                     # one rank, large image: the bands of rows already recomposed (below)
     if count > 0:
         # upload only the rows this rank's patches read (1/world of the tile), origins shifted into the slab
         my_org = org[first:first + count]
@@ -145,7 +146,6 @@ def _run(dsets, scales, patch, border, deep, run_60):
         # last tile row, patches.py:396-401) — and an event marks each band, so that the download can later run band by band
         # on a copy stream UNDER the batches still computing (a D2H takes 5-40 % of its own time away from the kernels,
         # profiles/r04_ablation.md §3).  This loop still only enqueues.
-        bands = None
         if world == 1 and not single and _pinned_wanted((int(size[0]), int(size[1]), cout)) and \
                 os.environ.get('DSEN2_BANDED_OUTPUT', '1') != '0':
             bands = dict(x_tiles=_patches.recompose_grid(size, patch, border)[0], rows=0, list=[],
