@@ -168,6 +168,26 @@ def test_bf16x3_dsen2_20_on_the_whole_bundled_tiles(golden_dir, tmp_path, monkey
     assert out.shape == (600, 600, 6) and err < RMSE_GATE and err < X3_EXPECTED
 
 
+def test_bf16x3_dsen2_60_on_a_whole_bundled_tile(golden_dir, tmp_path, monkeypatch):
+    """DSen2_60 (12-band input, two up-sampling passes, 16 patches of 192^2) in bf16x3 on a tile the reference ships."""
+    from dsen2_amd import supres
+    flat = do.he_uniform_weights(12, 2, 6, 128, seed=32, bias_scale=0.02)
+    np.save(str(tmp_path / 's2_030_lr_1e-05.npy'), flat)
+    monkeypatch.setattr(supres, 'MDL_PATH', str(tmp_path) + os.sep)
+    monkeypatch.setattr(supres, 'PRECISION', 'bf16x3')
+    supres.clear_model_cache()
+    g = np.load(os.path.join(golden_dir, 'tile_T33UUB_600.npz'))
+    d = [g[k].astype(np.float32) for k in ('d10', 'd20', 'd60')]
+    out = quiet(supres.DSen2_60, d[0], d[1], d[2], deep=False)
+    supres.clear_model_cache()
+    p = po.get_test_patches60(d[0], d[1], d[2], patchSize=192, border=12, f32_coords=True)
+    pred = c_oracle.forward([a / np.float32(2000) for a in p], flat, 6, 128)
+    ref = quiet(po.recompose_images, pred, border=12, size=d[0].shape).astype(np.float64)
+    err = do.rmse(out.astype(np.float64) / 2000, ref)
+    print('T33UUB DSen2_60 bf16x3: normalised rmse %.3e' % err)
+    assert out.shape == (600, 600, 2) and err < RMSE_GATE and err < X3_EXPECTED
+
+
 @pytest.mark.parametrize('d,feat,n,h,w', [(2, 128, 2, 32, 32), (1, 256, 1, 21, 37), (3, 128, 1, 16, 33)])
 def test_precision2_forward_is_the_chain_of_its_kernel_level_operations(d, feat, n, h, w):
     """dsen2_model_forward with precision 2 against the same network assembled from the kernel-level entry points (first
