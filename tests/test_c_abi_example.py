@@ -4,7 +4,6 @@ on raw hipMalloc'ed buffers, giving the Python host's result for the same weight
 import os
 import shutil
 import subprocess
-import sys
 
 import numpy as np
 import pytest

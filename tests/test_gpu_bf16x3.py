@@ -48,7 +48,7 @@ def _hi_ties_away(x):
 def test_split3_planes_are_what_the_header_says():
     """dsen2_split3_f32: plane 0 = the bf16 rounding (ties away) of the bit pattern = dsen2_split_f32's hi; lo16 = its lo
     (the pair restores x bit for bit); plane 1 = bf16_rne(x - hi), so hi + xl carries 16 significant bits of x."""
-    from dsen2_amd.DSen2Net import from_blocked, join_f32, split3_f32, split_f32
+    from dsen2_amd.DSen2Net import join_f32, split3_f32, split_f32
     rng = np.random.default_rng(3)
     x = (rng.standard_normal((2, 5, 13, 128)) * np.exp(rng.uniform(-6, 6, (2, 5, 13, 128)))).astype(np.float32)
     xd = torch.from_numpy(x).cuda()

@@ -152,7 +152,6 @@ def test_forward_profile_closes_on_itself():
 def test_a_handle_belongs_to_the_device_it_was_created_on():
     """include/dsen2_hip.h: one handle per device — a call with another current device returns DSEN2_ERR_INVALID instead
     of handing device A's weights to kernels on device B.  (Needs two GPUs: skipped on a one-GPU box.)"""
-    import ctypes
     from dsen2_amd import _lib
     if torch.cuda.device_count() < 2:
         pytest.skip('one GPU visible: the mismatch cannot be produced')
