@@ -94,6 +94,27 @@ def test_dsen2_20_full_tile_identity_and_windows_vs_oracle(model_dir):
         assert err < RMSE_GATE_NORMALISED, which
 
 
+def test_dsen2_20_full_tile_in_bf16x3_stays_inside_the_fp32_gate(model_dir, monkeypatch):
+    """The opt-in bf16x3 arithmetic over all 9801 patches of the 10980^2 tile against the fp32 run of the same call (which the
+    test above ties to the oracle at 2e-6): the WHOLE image within the 1e-4 normalised gate, every band finite."""
+    from dsen2_amd import supres
+    rng = np.random.default_rng(2026)
+    d10 = rng.integers(35, 13110, size=(N, N, 4), dtype=np.uint16)
+    d20 = rng.integers(35, 13110, size=(N // 2, N // 2, 6), dtype=np.uint16)
+    ref = quiet(supres.DSen2_20, d10, d20, deep=False)
+    monkeypatch.setattr(supres, 'PRECISION', 'bf16x3')
+    out = quiet(supres.DSen2_20, d10, d20, deep=False)
+    assert out.shape == ref.shape == (N, N, 6) and not np.array_equal(out, ref)
+    err2 = 0.0
+    for r0 in range(0, N, 1098):                     # float64 accumulation in slabs: no 5.8 GB temporary
+        dlt = out[r0:r0 + 1098].astype(np.float64) - ref[r0:r0 + 1098]
+        assert np.isfinite(dlt).all()
+        err2 += float((dlt * dlt).sum())
+    err = np.sqrt(err2 / out.size) / 2000
+    print('10980^2 DSen2_20 bf16x3 vs fp32: normalised rmse %.3e over the whole image' % err)
+    assert err < 3e-5 < RMSE_GATE_NORMALISED
+
+
 def test_dsen2_60_full_tile_identity_and_a_window_vs_oracle(tmp_path, monkeypatch):
     """The other half of testing/s2_tiles_supres.py:332-342 at the real size: DSen2_60 over 10980^2 — 4356 patches of 192^2
     (borders 12 / 6 / 2, 60 m stride 28, crops x 6 / x 3 / x 1: patches.py:83-156) — run-to-run identity and the interior
