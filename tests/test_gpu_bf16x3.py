@@ -16,7 +16,6 @@ pytestmark = pytest.mark.gpu
 
 from oracle import c_oracle
 from oracle import dsen2_oracle as do
-from oracle import patches_oracle as po
 
 RMSE_GATE = 1e-4                    # BASELINE.md §2, normalised domain — the fp32 gate
 X3_EXPECTED = 3e-5                  # what the arithmetic should achieve at d = 6 (emulation: 1e-5); a regression alarm
@@ -147,9 +146,10 @@ def test_bf16x3_batch_512_properties_and_vdsen2_depth():
 
 
 @pytest.mark.parametrize('name', ['tile_T33UUB_600.npz', 'tile_T49JGM_600.npz'])
-def test_bf16x3_dsen2_20_on_the_whole_bundled_tiles(golden_dir, tmp_path, monkeypatch, name):
+def test_bf16x3_dsen2_20_on_the_whole_bundled_tiles(golden_dir, tmp_path, monkeypatch, oracle_dsen2_tile, name):
     """DSen2_20 through the drop-in surface with supres.PRECISION = 'bf16x3' on the two tiles the reference ships, all 36
-    patches against the float64 oracle pipeline: the fp32 gate."""
+    patches against the float64 oracle pipeline: the fp32 gate.  (Same weights as tests/test_gpu_bundled_tiles.py: the oracle
+    image is computed once per session.)"""
     from dsen2_amd import supres
     flat = do.he_uniform_weights(10, 6, 6, 128, seed=31, bias_scale=0.02)
     np.save(str(tmp_path / 's2_032_lr_1e-04.npy'), flat)
@@ -160,15 +160,13 @@ def test_bf16x3_dsen2_20_on_the_whole_bundled_tiles(golden_dir, tmp_path, monkey
     d10, d20 = g['d10'].astype(np.float32), g['d20'].astype(np.float32)
     out = quiet(supres.DSen2_20, d10, d20, deep=False)
     supres.clear_model_cache()
-    p = po.get_test_patches(d10, d20, patchSize=128, border=8, f32_coords=True)
-    pred = c_oracle.forward([a / np.float32(2000) for a in p], flat, 6, 128)
-    ref = quiet(po.recompose_images, pred, border=8, size=d10.shape).astype(np.float64)
-    err = do.rmse(out.astype(np.float64) / 2000, ref)
+    ref = oracle_dsen2_tile(name, flat)
+    err = do.rmse(out.astype(np.float64), ref) / 2000
     print('%s DSen2_20 bf16x3: normalised rmse %.3e' % (name, err))
     assert out.shape == (600, 600, 6) and err < RMSE_GATE and err < X3_EXPECTED
 
 
-def test_bf16x3_dsen2_60_on_a_whole_bundled_tile(golden_dir, tmp_path, monkeypatch):
+def test_bf16x3_dsen2_60_on_a_whole_bundled_tile(golden_dir, tmp_path, monkeypatch, oracle_dsen2_tile):
     """DSen2_60 (12-band input, two up-sampling passes, 16 patches of 192^2) in bf16x3 on a tile the reference ships."""
     from dsen2_amd import supres
     flat = do.he_uniform_weights(12, 2, 6, 128, seed=32, bias_scale=0.02)
@@ -180,10 +178,8 @@ def test_bf16x3_dsen2_60_on_a_whole_bundled_tile(golden_dir, tmp_path, monkeypat
     d = [g[k].astype(np.float32) for k in ('d10', 'd20', 'd60')]
     out = quiet(supres.DSen2_60, d[0], d[1], d[2], deep=False)
     supres.clear_model_cache()
-    p = po.get_test_patches60(d[0], d[1], d[2], patchSize=192, border=12, f32_coords=True)
-    pred = c_oracle.forward([a / np.float32(2000) for a in p], flat, 6, 128)
-    ref = quiet(po.recompose_images, pred, border=12, size=d[0].shape).astype(np.float64)
-    err = do.rmse(out.astype(np.float64) / 2000, ref)
+    ref = oracle_dsen2_tile('tile_T33UUB_600.npz', flat, run_60=True)
+    err = do.rmse(out.astype(np.float64), ref) / 2000
     print('T33UUB DSen2_60 bf16x3: normalised rmse %.3e' % err)
     assert out.shape == (600, 600, 2) and err < RMSE_GATE and err < X3_EXPECTED
 

@@ -16,9 +16,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from oracle import c_oracle
 from oracle import dsen2_oracle as do
-from oracle import patches_oracle as po
 
 TILES = ['tile_T33UUB_600.npz', 'tile_T49JGM_600.npz']
 TIGHT = dict(rtol=4e-7, atol=2e-3)          # tests/test_gpu_patches.py: a few float32 ulp of the captured reference output
@@ -85,36 +83,27 @@ def test_tiling_of_the_whole_bundled_tile_equals_the_reference_capture(golden_di
     np.testing.assert_allclose(rec60.astype(np.float64).sum(axis=0), g['rec60_cols'], rtol=1e-6)
 
 
-def oracle_image(p, flat, cout, patch, border, size):
-    """Oracle pipeline: /2000, float64 C oracle CNN on every patch, oracle recomposition, *2000 (testing/supres.py:23-29)."""
-    p = [a / np.float32(2000) for a in p]
-    pred = c_oracle.forward(p, flat, 6, 128)
-    return quiet(po.recompose_images, pred, border=border, size=size).astype(np.float64) * 2000
-
-
 @pytest.mark.parametrize('name', TILES)
-def test_dsen2_20_on_the_whole_bundled_tile(golden_dir, model_dir, name):
+def test_dsen2_20_on_the_whole_bundled_tile(golden_dir, model_dir, oracle_dsen2_tile, name):
     """DSen2_20(im10, im20) as testing/demoDSen2.py:42-43 calls it: all 36 patches against the float64 oracle."""
     from dsen2_amd.supres import DSen2_20
     _, d = bands(golden_dir, name)
     out = quiet(DSen2_20, d[0], d[1], deep=False)
     assert out.shape == (600, 600, 6) and out.dtype == np.float32 and np.isfinite(out).all()
-    p = po.get_test_patches(d[0], d[1], patchSize=128, border=8, f32_coords=True)
-    ref = oracle_image(p, model_dir['s2_032_lr_1e-04'], 6, 128, 8, d[0].shape)
+    ref = oracle_dsen2_tile(name, model_dir['s2_032_lr_1e-04'])
     err = do.rmse(out, ref) / 2000
     print('%s DSen2_20: normalised rmse %.3e' % (name, err))
     assert err < RMSE_GATE_NORMALISED
 
 
 @pytest.mark.parametrize('name', TILES)
-def test_dsen2_60_on_the_whole_bundled_tile(golden_dir, model_dir, name):
+def test_dsen2_60_on_the_whole_bundled_tile(golden_dir, model_dir, oracle_dsen2_tile, name):
     """DSen2_60(im10, im20, im60) as testing/demoDSen2.py:67-68 calls it: all 16 patches against the float64 oracle."""
     from dsen2_amd.supres import DSen2_60
     _, d = bands(golden_dir, name)
     out = quiet(DSen2_60, d[0], d[1], d[2], deep=False)
     assert out.shape == (600, 600, 2) and out.dtype == np.float32 and np.isfinite(out).all()
-    p = po.get_test_patches60(d[0], d[1], d[2], patchSize=192, border=12, f32_coords=True)
-    ref = oracle_image(p, model_dir['s2_030_lr_1e-05'], 2, 192, 12, d[0].shape)
+    ref = oracle_dsen2_tile(name, model_dir['s2_030_lr_1e-05'], run_60=True)
     err = do.rmse(out, ref) / 2000
     print('%s DSen2_60: normalised rmse %.3e' % (name, err))
     assert err < RMSE_GATE_NORMALISED
