@@ -187,7 +187,9 @@ def main():
         #     convolutions, output convolution — consecutive intervals between the same time stamps, so
         #     launches x ms_per_launch + first_ms + out_ms = forward_ms by construction
         #     (3 plain passes are enqueued right before them, no synchronisation in between: the GPU is at its steady clock)
-        prof = model.profile_forward(xs, out=outs[0], iters=args.steps, warm=3)
+        # at least `steps` instrumented passes, up to 100 while they stay within ~1.5 s (1.3 s at the default config): a stable mean
+        n_prof = max(args.steps, min(100, int(1500.0 / max(ms_per_step, 1e-3))))
+        prof = model.profile_forward(xs, out=outs[0], iters=n_prof, warm=3)
         ms = prof['body_ms'] / (2 * NUM_LAYERS)
         # (1b) the same passes WITHOUT the events inside them, right after and equally warm (the kernels run on torch's
         #     current stream, so two torch events bracket them): what the four event records per forward cost, and whether
@@ -196,11 +198,11 @@ def main():
             model.forward_device(xs, out=outs[0])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(args.steps):
+        for _ in range(n_prof):
             model.forward_device(xs, out=outs[0])
         e1.record()
         torch.cuda.synchronize()
-        replay_ms = e0.elapsed_time(e1) / args.steps
+        replay_ms = e0.elapsed_time(e1) / n_prof
         # (2) each epilogue alone, back to back, on dense random operands (no ReLU zeros: the chip clocks lower)
         x3 = cfg['precision'] == 'bf16x3'
         ms_relu = ms_res = None
@@ -240,7 +242,7 @@ def main():
                                   else 'bf16 MFMA 16x16x32, LDS-DMA staging, 16x32-pixel items' if bf else 'fp32 MFMA 32x32x2, LDS-DMA staging',
                                   '; ONE launch over all %d body convolutions, a workgroup owns its patches through every layer' % (2 * NUM_LAYERS) if launches == 1 else ''),
                               'ms_per_launch': round(ms * per_launch, 4),
-                              'ms_per_launch_source': 'HIP events on the launch stream around the %d body-conv launch%s of each of %d forward passes (4 events per pass)' % (launches, '' if launches == 1 else 'es', args.steps),
+                              'ms_per_launch_source': 'HIP events on the launch stream around the %d body-conv launch%s of each of %d forward passes (4 events per pass)' % (launches, '' if launches == 1 else 'es', n_prof),
                               'launches_per_forward': launches, 'convolutions_per_launch': per_launch, 'ms_per_convolution': round(ms, 4),
                               # the line closes on itself: launches x ms_per_launch + first_ms + out_ms = forward_ms (same events)
                               'forward_ms': round(prof['forward_ms'], 4), 'first_ms': round(prof['first_ms'], 4),
