@@ -272,3 +272,36 @@ def test_recompose_rows_is_the_full_recomposition_cut_into_bands():
         gp.recompose_rows_device(a, 4, img, 10, 81)
     with pytest.raises(_lib.DSen2Error):
         gp.recompose_rows_device(a, 4, img, 30, 20)
+
+
+def test_smallest_images_the_tiling_accepts(model_dir):
+    """The smallest images whose symmetric padding still covers one patch: 112 x 112 for DSen2_20 (ONE used patch of the four
+    the reference allocates, patches.py:35) and 168 x 168 for DSen2_60, plus one pixel row / 60 m cell more (a clamped second
+    patch that overlaps the first almost completely) — each against the oracle pipeline."""
+    from dsen2_amd.supres import DSen2_20, DSen2_60
+    rng = np.random.default_rng(8)
+    for h, w in ((112, 112), (114, 112), (112, 124)):
+        d10 = rng.integers(35, 6000, size=(h, w, 4)).astype(np.float32)
+        d20 = rng.integers(35, 6000, size=(h // 2, w // 2, 6)).astype(np.float32)
+        out, _ = quiet(DSen2_20, d10, d20, deep=False)
+        assert out.shape == (h, w, 6)
+        p10, p20 = po.get_test_patches(d10, d20, patchSize=128, border=8, f32_coords=True)
+        used = int(np.ceil(h / 112.0) * np.ceil(w / 112.0))
+        pred = np.zeros((p10.shape[0], 6, 128, 128))
+        pred[:used] = c_oracle.forward([p10[:used] / np.float32(2000), p20[:used] / np.float32(2000)], model_dir['s2_032_lr_1e-04'], 6, 128)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = po.recompose_images(pred, border=8, size=d10.shape).astype(np.float64) * 2000
+        assert do.rmse(out, ref) / 2000 < RMSE_GATE_NORMALISED, (h, w)
+    for h, w in ((168, 168), (174, 168)):
+        d10 = rng.integers(35, 6000, size=(h, w, 4)).astype(np.float32)
+        d20 = rng.integers(35, 6000, size=(h // 2, w // 2, 6)).astype(np.float32)
+        d60 = rng.integers(35, 6000, size=(h // 6, w // 6, 2)).astype(np.float32)
+        out, _ = quiet(DSen2_60, d10, d20, d60, deep=False)
+        assert out.shape == (h, w, 2)
+        p = po.get_test_patches60(d10, d20, d60, patchSize=192, border=12, f32_coords=True)
+        used = int(np.ceil(h / 168.0) * np.ceil(w / 168.0))
+        pred = np.zeros((p[0].shape[0], 2, 192, 192))
+        pred[:used] = c_oracle.forward([a[:used] / np.float32(2000) for a in p], model_dir['s2_030_lr_1e-05'], 6, 128)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = po.recompose_images(pred, border=12, size=d10.shape).astype(np.float64) * 2000
+        assert do.rmse(out, ref) / 2000 < RMSE_GATE_NORMALISED, (h, w)
