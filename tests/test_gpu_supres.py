@@ -305,3 +305,27 @@ def test_smallest_images_the_tiling_accepts(model_dir):
         with contextlib.redirect_stdout(io.StringIO()):
             ref = po.recompose_images(pred, border=12, size=d10.shape).astype(np.float64) * 2000
         assert do.rmse(out, ref) / 2000 < RMSE_GATE_NORMALISED, (h, w)
+
+
+def test_any_real_dtype_and_memory_layout_gives_the_float32_result(model_dir):
+    """testing/supres.py takes whatever GDAL's ReadAsArray returns ("any real dtype": np.pad + a float32 patch array,
+    patches.py:27-28,37-39): uint16 (Sentinel-2 L1C), int16, int32, uint8-range, float64, a Fortran-ordered array, a
+    non-contiguous view and a read-only array all give the bits of the float32 C-contiguous call."""
+    from dsen2_amd.supres import DSen2_20
+    rng = np.random.default_rng(9)
+    base10 = rng.integers(35, 9000, size=(226, 150, 4))
+    base20 = rng.integers(35, 9000, size=(113, 75, 6))
+    want, _ = quiet(DSen2_20, base10.astype(np.float32), base20.astype(np.float32), deep=False)
+    for cast in (np.uint16, np.int16, np.int32, np.float64):
+        got, _ = quiet(DSen2_20, base10.astype(cast), base20.astype(cast), deep=False)
+        assert np.array_equal(got, want), cast
+    f10, f20 = np.asfortranarray(base10.astype(np.float32)), np.asfortranarray(base20.astype(np.uint16))
+    assert np.array_equal(quiet(DSen2_20, f10, f20, deep=False)[0], want)
+    wide10 = np.zeros((226, 150, 9), np.uint16); wide10[:, :, ::2][:, :, :4] = base10
+    view10 = wide10[:, :, 0:7:2]                                   # strided channel view
+    assert not view10.flags.c_contiguous
+    ro20 = base20.astype(np.uint16); ro20.setflags(write=False)
+    assert np.array_equal(quiet(DSen2_20, view10, ro20, deep=False)[0], want)
+    small = (base10 % 256).astype(np.uint8), (base20 % 256).astype(np.uint8)
+    want8, _ = quiet(DSen2_20, small[0].astype(np.float32), small[1].astype(np.float32), deep=False)
+    assert np.array_equal(quiet(DSen2_20, small[0], small[1], deep=False)[0], want8)
