@@ -235,3 +235,36 @@ def test_one_model_on_two_streams_and_two_threads(precision):
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     m.release_workspaces()
     assert torch.equal(m.forward_device(ins[0]), want[0])
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
+def test_a_nan_pixel_stays_inside_its_receptive_field(precision):
+    """A NaN input pixel (Sentinel-2 rasters are integers, so this is outside the parity claim — and the reference itself is
+    not well defined here: Eigen's vectorised `cwiseMax` of TF 1.x returns 0 for relu(NaN), its scalar tail NaN) changes
+    nothing outside the receptive field of that pixel (14 pixels: 1 + 2 * 6 + 1 convolutions of 3 x 3) and nothing of any other
+    patch, bit for bit.  Here relu is `fmaxf(v, 0)`: the first ReLU turns the poisoned activations into zeros, so a NaN in a
+    10 m band leaves every output finite; a NaN in a 20 m band also reaches the output through the skip connection
+    (DSen2Net.py:41) — at exactly that pixel and band.  Screens the zero padding (materialised by out-of-range loads, not by
+    multiplying by zero), the tile halos and the plane formats of the bf16 modes for stray contamination."""
+    from dsen2_amd.DSen2Net import s2model
+    flat = do.he_uniform_weights(10, 6, 6, 128, seed=3, bias_scale=0.05)
+    m = s2model(((4, None, None), (6, None, None)), num_layers=6, feature_size=128, precision=precision)
+    m.set_weights_flat(flat)
+    xs = [torch.from_numpy(a).cuda() for a in do.synthetic_inputs(5, 48, 40, (4, 6), seed=2)]
+    clean = m.forward_device(xs).clone()
+    assert bool(torch.isfinite(clean).all())
+    py, px = 30, 7                                                    # near the left edge and a 16 / 32-pixel tile boundary
+    yy, xx = torch.meshgrid(torch.arange(48, device='cuda'), torch.arange(40, device='cuda'), indexing='ij')
+    inside = ((yy - py).abs() <= 14) & ((xx - px).abs() <= 14)
+    xs[0][2, 1, py, px] = float('nan')                                # a 10 m band
+    dirty = m.forward_device(xs).clone()
+    assert torch.equal(dirty[[0, 1, 3, 4]], clean[[0, 1, 3, 4]])      # other patches: bit-identical
+    assert torch.equal(dirty[2][:, ~inside], clean[2][:, ~inside])    # outside the receptive field: bit-identical
+    assert bool(torch.isfinite(dirty).all())                          # swallowed by the first ReLU
+    assert not torch.equal(dirty[2][:, inside], clean[2][:, inside])  # ... but the neighbourhood did change
+    xs[0][2, 1, py, px] = 1.0
+    xs[1][2, 4, py, px] = float('nan')                                # a 20 m band: also the skip input of output band 4
+    dirty = m.forward_device(xs)
+    bad = ~torch.isfinite(dirty)
+    assert int(bad.sum()) == 1 and bool(bad[2, 4, py, px])
+    assert torch.equal(dirty[[0, 1, 3, 4]], clean[[0, 1, 3, 4]]) and torch.equal(dirty[2][:, ~inside], clean[2][:, ~inside])
