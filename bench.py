@@ -141,6 +141,14 @@ def main():
                 pending[b].wait()
                 pending[b] = None
 
+    # Untimed, before the W warm-up steps: at least ~40 ms of forwards.  After an idle stretch (process start, weight upload) the
+    # chip needs ~25 ms of work to reach its steady clock (profiles/r04_ablation.md §2); W steps of a SHORT step (bf16: 1.8 ms)
+    # would leave the timed loop inside that ramp.  The headline config's W x 12.8 ms covers it anyway.
+    torch.cuda.synchronize()
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.040:
+        model.forward_device(xs, out=outs[0])
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     drain()
