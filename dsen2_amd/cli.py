@@ -246,9 +246,12 @@ class GdalProduct(object):
         def same_zone(cands):
             hit = [c for c in cands if self.utm and self.utm in c[1]]
             return (hit or cands[idx:idx + 1] or cands[:1] or [None])[0]
-        self.ds = {'10m': gdal.Open(tens[idx][0]), '20m': gdal.Open(same_zone(groups['20m'])[0])}
+        s20 = same_zone(groups['20m'])
+        self.ds = {'10m': gdal.Open(tens[idx][0]), '20m': gdal.Open(s20[0])}
         s60 = same_zone(groups['60m'])
         self.ds['60m'] = gdal.Open(s60[0]) if s60 else None
+        # the descriptions of the selected sub-datasets: the reference names them when it loads the data (:312,318,325)
+        self.sub_desc = {'10m': tens[idx][1], '20m': s20[1], '60m': s60[1] if s60 else ''}
         # bands by short name, in sub-dataset order; a name is consumed once (:257-292)
         want = list(want)
         self.names, self.index, self.descriptions = {}, {}, {}
@@ -448,10 +451,15 @@ def _run(args):
         if args.list_bands:                                        # :229-239, then the selection lines, then exit (:295-296)
             for line in product.band_listing():
                 print(line)
-        for key in ('10m', '20m', '60m'):
-            print('Selected %s bands: %s' % (key, ' '.join(product.names[key])))
+        for key in ('10m', '20m', '60m'):                          # (:257-292: "Selected 10m bands:" + " name" per band)
+            print('Selected %s bands:%s' % (key, ''.join(' ' + n for n in product.names[key])))
         if args.list_bands:
             return 0
+        if not args.output_file:                                   # :298-301 (the reference goes on, with the input's name)
+            print('Error: you must provide the name of an output file. I will set it identical to the input...')
+        for key in ('10m', '20m', '60m'):                          # :311-329
+            if product.index[key]:
+                print('Loading selected data from: %s' % product.sub_desc[key])
         from . import dist as _dist
         if _dist.rank_world()[1] > 1:
             # one process per GPU: each reads the rows its patches need, when DSen2_20 / DSen2_60 ask for them
