@@ -6,7 +6,7 @@ The reference demo needs the trained checkpoints and ground-truth tiles, all str
 (Copernicus Sentinel data, CC BY 4.0, committed as uint16 under tests/golden/): --tile crop (default: a 264x264 crop of
 T33UUB, seconds), --tile T33UUB or --tile T49JGM (the whole 600x600 tiles, as testing/demoDSen2.py:42-43,67-68 reads
 them from data/*.mat; about a minute of float64 oracle), or --tile FILE (.npz / .mat, via dsen2_amd.cli._load), with either
-  * --models DIR : real checkpoints (keras .hdf5 with h5py, or converted .npy) -> super-resolved bands, or
+  * --models DIR : real checkpoints (keras .hdf5, or converted .npy) -> super-resolved bands, or
   * default      : seeded random-init weights, compared against the float64 oracle pipeline so the printed
                    RMSE is a parity figure, printed in the reference's format ("RMSE: %.4f").
 """

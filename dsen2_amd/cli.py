@@ -13,7 +13,7 @@
 
 Two kinds of INPUT:
   * an array file — .npz with keys data10 [x,y,4], data20 [x/2,y/2,6], data60 [x/6,y/6,2] (aliases d10/d20/d60),
-    or a MATLAB v7.3 .mat with im10/im20/im60 as in the reference's data/*.mat (needs h5py; CHW, transposed like
+    or a MATLAB v7.3 .mat with im10/im20/im60 as in the reference's data/*.mat (read by hdf5_min.py; CHW, transposed like
     testing/demoDSen2.py:14-28).  Output: np.savez(output, bands={description: 2-D array}) exactly like the
     reference's npz fallback (s2_tiles_supres.py:419-420).
   * anything else (a Sentinel-2 .zip / SAFE .xml) is opened with GDAL when `osgeo` is importable: sub-dataset and
@@ -92,13 +92,11 @@ def _load(path, lazy=False):
             return None
         return pick('data10', 'd10'), pick('data20', 'd20'), pick('data60', 'd60')
     if ext == '.mat':
-        try:
-            import h5py
-        except ImportError as e:
-            raise ImportError('reading .mat needs h5py; convert to .npz with keys data10/data20/data60') from e
-        with h5py.File(path, 'r') as f:        # testing/demoDSen2.py:14-28 (readh5): CHW -> HWC
-            get = lambda k: np.array(f[k]).transpose() if k in f else None
-            return get('im10'), get('im20'), get('im60')
+        from . import hdf5_min                 # MATLAB v7.3 = HDF5 behind a 512-byte user block; no h5py needed
+        # testing/demoDSen2.py:14-28 (readh5): CHW -> HWC
+        return hdf5_min.read_with(path, lambda f: tuple(np.array(f[k]).transpose() if k in f else None
+                                                        for k in ('im10', 'im20', 'im60')),
+                                  'convert to .npz with keys data10/data20/data60')
     raise ValueError('unsupported input %r (use .npz or .mat)' % path)
 
 

@@ -118,7 +118,7 @@ def gather_to_root(send, total, dst=0):
 def load_weights_on_root(path, cin, cout, num_layers, feature_size, device=None, src=0):
     """C1 as the product path uses it (supres._get_model under an initialised process group): rank `src` alone opens and
     parses the checkpoint (the stand-in for `model.load_weights(predict_file)`, testing/supres.py:63), every rank gets the
-    keras-flat float32 vector by ONE broadcast — the file (and h5py, for a keras .hdf5) is needed on rank `src` only.
+    keras-flat float32 vector by ONE broadcast — the file is needed on rank `src` only.
     A failure on the root is a failure everywhere: a one-element status goes first, so that no rank is left waiting in the
     data broadcast; the root re-raises its own exception (OSError for a missing file, like keras), the others an OSError
     naming the file and the root."""

@@ -58,7 +58,7 @@ def _get_model(input_shape, deep, run_60):
         print('Symbolic Model Created.')
         if _dist.rank_world()[1] > 1:
             # one process per GPU: rank 0 alone reads the checkpoint, one RCCL broadcast delivers it (C1, dsen2_amd/dist.py)
-            # — the file need not exist on (and h5py need not be installed for) any other rank.  Collective: every rank
+            # — the file need not exist on any other rank.  Collective: every rank
             # gets here on its first call for this architecture, all of them make the same calls.
             model.set_weights_flat(_dist.load_weights_on_root(predict_file, model.cin, model.cout, num_layers, feature_size,
                                                               device=dev))

@@ -6,7 +6,7 @@
 
 Files accepted by load_flat():
   *.npy / *.npz['flat']   a flat array in that order (what tools/convert_keras_hdf5.py writes)
-  *.hdf5 / *.h5           a keras checkpoint as saved by training/supres_train.py:195-201 (needs h5py)
+  *.hdf5 / *.h5           a keras checkpoint as saved by training/supres_train.py:195-201 (read by hdf5_min.py; no h5py needed)
 """
 import os
 
@@ -39,62 +39,75 @@ def random_he_uniform(cin, cout, num_layers, feature_size, seed=1, bias_scale=0.
 
 
 def _from_keras_hdf5(path, shapes):
-    try:
-        import h5py
-    except ImportError as e:   # pragma: no cover - depends on the host
-        raise ImportError('reading a keras .hdf5 checkpoint needs h5py; convert it once with '
-                          'tools/convert_keras_hdf5.py on a machine that has h5py and load the .npy') from e
+    from . import hdf5_min
+    return hdf5_min.read_with(path, lambda f: _from_keras_group(f, path, shapes),
+                              'convert it once with tools/convert_keras_hdf5.py where h5py is')
+
+
+def _from_keras_group(f, path, shapes):
     import re
     parts = []
-    with h5py.File(path, 'r') as f:
-        root = f['model_weights'] if 'model_weights' in f else f
-        _s = lambda n: n.decode() if isinstance(n, bytes) else str(n)
-        names = [_s(n) for n in root.attrs['layer_names']] if 'layer_names' in root.attrs else list(root.keys())
-        convs = []
-        for lname in names:
-            grp = root[lname]
-            wn = [_s(n) for n in grp.attrs.get('weight_names', [])]
-            if not wn:
-                continue                       # Input / Concatenate / Activation / Lambda / Add carry no weights
-            # a Conv2D holds exactly '<layer>/kernel:0' and '<layer>/bias:0' — picked by NAME, not by position
-            kern = [n for n in wn if n.split('/')[-1].startswith('kernel')]
-            bias = [n for n in wn if n.split('/')[-1].startswith('bias')]
-            if len(wn) != 2 or len(kern) != 1 or len(bias) != 1:
-                raise ValueError('%s: layer %r holds weights %r, expected one kernel and one bias' % (path, lname, wn))
-            # (the weight's own path is what is read: a name scope TensorFlow made unique — 'conv2d_1_1/kernel:0' under
-            # layer 'conv2d_1' — is legitimate)
-            m = re.search(r'(\d+)$', lname)
-            # multi-backend keras numbers from conv2d_1; tf.keras calls the session's first layer plain 'conv2d'
-            convs.append((int(m.group(1)) if m else 0, lname, np.asarray(grp[kern[0]]), np.asarray(grp[bias[0]])))
-        if len(convs) != len(shapes):
-            raise ValueError('%s holds %d conv layers, the architecture has %d' % (path, len(convs), len(shapes)))
+    root = f['model_weights'] if 'model_weights' in f else f
+    _s = lambda n: n.decode() if isinstance(n, bytes) else str(n)
 
-        def mismatch(order):
-            for (_, lname, k, b), (a, o) in zip(order, shapes):
-                if k.shape != (3, 3, a, o) or b.shape != (o,):
-                    return 'layer %s: shape %s/%s does not match (3,3,%d,%d)' % (lname, k.shape, b.shape, a, o)
-            return None
-        # Graph order (utils/DSen2Net.py:29-35) is the order the Conv2D layers were created = their numeric suffix
-        # (conv2d_7, conv2d_8, ... when other models were built in the same session).  Names without a usable
-        # numbering (missing or repeated suffixes) fall back to the file's layer_names order.  Either way the order
-        # must chain: Cin of the first layer, F -> F through the body, Cout of the last.
-        orders = []
-        if len(set(c[0] for c in convs)) == len(convs):
-            orders.append(sorted(convs, key=lambda c: c[0]))
-        orders.append(convs)
-        errors = [mismatch(o) for o in orders]
-        if all(errors):
-            raise ValueError('%s: %s' % (path, errors[0]))
-        chosen = orders[errors.index(None)]
-        if errors.index(None) == len(orders) - 1 and (len(orders) == 1 or errors[0] is not None):
-            # The fallback: the file's own layer_names order.  The shape chain cannot tell the 2d body layers (all F -> F)
-            # apart, so a file whose layer_names are not in creation order would load with permuted body weights — say
-            # which order was trusted instead of loading silently.
-            import warnings
-            warnings.warn('%s: conv layer names carry no usable numbering; trusting the file\'s layer_names order: %s'
-                          % (path, ', '.join(c[1] for c in chosen)), RuntimeWarning, stacklevel=3)
-        for _, _, k, b in chosen:
-            parts += [k.astype(np.float32).ravel(), b.astype(np.float32)]
+    def attr_list(obj, name):
+        # keras' load_attributes_from_hdf5_group: a list too long for one object-header message (64 KB) is saved in
+        # pieces name0, name1, ...
+        if name in obj.attrs:
+            return [_s(n) for n in obj.attrs[name]]
+        out, i = [], 0
+        while '%s%d' % (name, i) in obj.attrs:
+            out += [_s(n) for n in obj.attrs['%s%d' % (name, i)]]
+            i += 1
+        return out if i else None
+    names = attr_list(root, 'layer_names')
+    if names is None:
+        names = list(root.keys())
+    convs = []
+    for lname in names:
+        grp = root[lname]
+        wn = attr_list(grp, 'weight_names') or []
+        if not wn:
+            continue                       # Input / Concatenate / Activation / Lambda / Add carry no weights
+        # a Conv2D holds exactly '<layer>/kernel:0' and '<layer>/bias:0' — picked by NAME, not by position
+        kern = [n for n in wn if n.split('/')[-1].startswith('kernel')]
+        bias = [n for n in wn if n.split('/')[-1].startswith('bias')]
+        if len(wn) != 2 or len(kern) != 1 or len(bias) != 1:
+            raise ValueError('%s: layer %r holds weights %r, expected one kernel and one bias' % (path, lname, wn))
+        # (the weight's own path is what is read: a name scope TensorFlow made unique — 'conv2d_1_1/kernel:0' under
+        # layer 'conv2d_1' — is legitimate)
+        m = re.search(r'(\d+)$', lname)
+        # multi-backend keras numbers from conv2d_1; tf.keras calls the session's first layer plain 'conv2d'
+        convs.append((int(m.group(1)) if m else 0, lname, np.asarray(grp[kern[0]]), np.asarray(grp[bias[0]])))
+    if len(convs) != len(shapes):
+        raise ValueError('%s holds %d conv layers, the architecture has %d' % (path, len(convs), len(shapes)))
+
+    def mismatch(order):
+        for (_, lname, k, b), (a, o) in zip(order, shapes):
+            if k.shape != (3, 3, a, o) or b.shape != (o,):
+                return 'layer %s: shape %s/%s does not match (3,3,%d,%d)' % (lname, k.shape, b.shape, a, o)
+        return None
+    # Graph order (utils/DSen2Net.py:29-35) is the order the Conv2D layers were created = their numeric suffix
+    # (conv2d_7, conv2d_8, ... when other models were built in the same session).  Names without a usable
+    # numbering (missing or repeated suffixes) fall back to the file's layer_names order.  Either way the order
+    # must chain: Cin of the first layer, F -> F through the body, Cout of the last.
+    orders = []
+    if len(set(c[0] for c in convs)) == len(convs):
+        orders.append(sorted(convs, key=lambda c: c[0]))
+    orders.append(convs)
+    errors = [mismatch(o) for o in orders]
+    if all(errors):
+        raise ValueError('%s: %s' % (path, errors[0]))
+    chosen = orders[errors.index(None)]
+    if errors.index(None) == len(orders) - 1 and (len(orders) == 1 or errors[0] is not None):
+        # The fallback: the file's own layer_names order.  The shape chain cannot tell the 2d body layers (all F -> F)
+        # apart, so a file whose layer_names are not in creation order would load with permuted body weights — say
+        # which order was trusted instead of loading silently.
+        import warnings
+        warnings.warn('%s: conv layer names carry no usable numbering; trusting the file\'s layer_names order: %s'
+                      % (path, ', '.join(c[1] for c in chosen)), RuntimeWarning, stacklevel=3)
+    for _, _, k, b in chosen:
+        parts += [k.astype(np.float32).ravel(), b.astype(np.float32)]
     return np.concatenate(parts)
 
 

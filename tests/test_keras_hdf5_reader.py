@@ -151,3 +151,32 @@ def test_cli_reads_the_tiles_the_reference_ships(mat, golden):
     assert str(g['source']) == mat
     for got, key in ((d10, 'd10'), (d20, 'd20'), (d60, 'd60')):
         assert np.array_equal(got, g[key].astype(got.dtype)), key
+
+
+def _same_tree(mine, theirs, where=''):
+    assert mine.keys() == list(theirs.keys()), where
+    assert set(mine.attrs) == set(theirs.attrs.keys()), where
+    for k in mine.attrs:
+        a, b = np.asarray(mine.attrs[k]), np.asarray(theirs.attrs[k])
+        assert a.shape == b.shape and [str(x) for x in a.ravel()] == [str(x) for x in b.ravel()], (where, k)
+    for k in mine.keys():
+        x, y = mine[k], theirs[k]
+        if isinstance(y, h5py.Group):
+            _same_tree(x, y, where + '/' + k)
+        else:
+            a, b = np.asarray(x), np.asarray(y)
+            assert a.dtype == b.dtype.newbyteorder('=') and a.shape == b.shape and a.tobytes() == b.astype(a.dtype).tobytes(), (where, k)
+
+
+def test_own_reader_and_h5py_agree_and_the_own_reader_is_the_one_used(tmp_path, monkeypatch):
+    """The product reads HDF5 through dsen2_amd/hdf5_min.py (h5py is only the fall-back for format features that reader
+    names as unsupported): on a full-size checkpoint written by h5py the two read the same tree, and load_flat does not
+    touch h5py."""
+    from dsen2_amd import hdf5_min, weights as W
+    flat = W.random_he_uniform(10, 6, 6, 128, seed=11, bias_scale=0.1)
+    p = str(tmp_path / 's2_032_lr_1e-04.hdf5')
+    write_keras_like(p, 10, 6, 6, 128, flat, first_index=7)
+    with hdf5_min.File(p) as mine, h5py.File(p, 'r') as theirs:
+        _same_tree(mine, theirs)
+    monkeypatch.setattr(h5py, 'File', lambda *a, **k: (_ for _ in ()).throw(AssertionError('h5py used')))
+    assert np.array_equal(W.load_flat(p, 10, 6, 6, 128), flat)

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Convert the reference's keras checkpoints (models/s2_03x_lr_*.hdf5, saved by training/supres_train.py:195-201
 as FULL models, so the weights sit under /model_weights/<layer>/<layer>/{kernel:0,bias:0}) into the flat .npy
-that dsen2_amd loads without h5py.
+(optional: dsen2_amd reads the .hdf5 itself through dsen2_amd/hdf5_min.py; the .npy loads faster and is
+what to ship when the checkpoint uses an HDF5 feature that reader does not implement).
 
-    python tools/convert_keras_hdf5.py models/s2_032_lr_1e-04.hdf5 [more.hdf5 ...]      (needs h5py)
+    python tools/convert_keras_hdf5.py models/s2_032_lr_1e-04.hdf5 [more.hdf5 ...]
 writes models/s2_032_lr_1e-04.npy next to each input; dsen2_amd.weights.load_flat() picks it up when asked for
 the .hdf5 name (testing/supres.py:55-60 file naming is kept).
 The architecture is inferred from the file name exactly as supres.py selects it:
