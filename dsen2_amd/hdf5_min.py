@@ -48,6 +48,13 @@ class _Buf(object):
             return None
         return self.base + int.from_bytes(raw, 'little')
 
+    def off_from(self, data, pos):
+        """The same for an address field inside a message body that has already been read."""
+        raw = data[pos:pos + self.O]
+        if raw == b'\xff' * self.O:
+            return None
+        return self.base + int.from_bytes(raw, 'little')
+
     def length(self, pos):
         return int.from_bytes(self.mm[pos:pos + self.L], 'little')
 
@@ -69,7 +76,7 @@ class _Type(object):
 
 def _parse_datatype(raw):
     cls, ver = raw[0] & 15, raw[0] >> 4
-    b0, b1 = raw[1], raw[2]
+    b0 = raw[1]
     size = int.from_bytes(raw[4:8], 'little')
     if cls == 0:                                                         # fixed-point
         prec = int.from_bytes(raw[10:12], 'little')
@@ -174,16 +181,6 @@ def _read_object_header(buf, addr):
             elif mtype != 0:
                 msgs.append(_Message(mtype, mflags, data))
     return msgs
-
-
-def _off_from(self, data, pos):
-    raw = data[pos:pos + self.O]
-    if raw == b'\xff' * self.O:
-        return None
-    return self.base + int.from_bytes(raw, 'little')
-
-
-_Buf.off_from = _off_from
 
 
 # ------------------------------------------------------------------------------------------------- groups (old style)
