@@ -87,25 +87,32 @@ def _from_keras_group(f, path, shapes):
             if k.shape != (3, 3, a, o) or b.shape != (o,):
                 return 'layer %s: shape %s/%s does not match (3,3,%d,%d)' % (lname, k.shape, b.shape, a, o)
         return None
-    # Graph order (utils/DSen2Net.py:29-35) is the order the Conv2D layers were created = their numeric suffix
-    # (conv2d_7, conv2d_8, ... when other models were built in the same session).  Names without a usable
-    # numbering (missing or repeated suffixes) fall back to the file's layer_names order.  Either way the order
-    # must chain: Cin of the first layer, F -> F through the body, Cout of the last.
-    orders = []
-    if len(set(c[0] for c in convs)) == len(convs):
-        orders.append(sorted(convs, key=lambda c: c[0]))
-    orders.append(convs)
-    errors = [mismatch(o) for o in orders]
-    if all(errors):
-        raise ValueError('%s: %s' % (path, errors[0]))
-    chosen = orders[errors.index(None)]
-    if errors.index(None) == len(orders) - 1 and (len(orders) == 1 or errors[0] is not None):
-        # The fallback: the file's own layer_names order.  The shape chain cannot tell the 2d body layers (all F -> F)
-        # apart, so a file whose layer_names are not in creation order would load with permuted body weights — say
-        # which order was trusted instead of loading silently.
-        import warnings
-        warnings.warn('%s: conv layer names carry no usable numbering; trusting the file\'s layer_names order: %s'
-                      % (path, ', '.join(c[1] for c in chosen)), RuntimeWarning, stacklevel=3)
+    # keras' load_weights (testing/supres.py:63) pairs the k-th weighted layer of the FILE's layer_names with the k-th weighted
+    # layer of the model; for s2model's chain that is graph order (utils/DSen2Net.py:29-35) = the order the Conv2D layers were
+    # created = their numeric suffix (conv2d_7, conv2d_8, ... when other models were built in the same session).  Both orders
+    # are formed; the one used must chain (Cin of the first layer, F -> F through the body, Cout of the last):
+    #   both chain and agree      -> that order (every checkpoint s2model can have written)
+    #   only one chains           -> that one (a file whose layer_names were reordered still loads by its numbering)
+    #   both chain but differ     -> the file's order, as keras would, with a warning that names both
+    #   no usable numbering       -> the file's order, with a warning: the shape chain cannot tell the 2d body layers apart
+    import warnings
+    by_file = convs
+    by_number = sorted(convs, key=lambda c: c[0]) if len(set(c[0] for c in convs)) == len(convs) else None
+    err_file, err_number = mismatch(by_file), (mismatch(by_number) if by_number is not None else 'no usable numbering')
+    if err_file and err_number:
+        raise ValueError('%s: %s' % (path, err_file if by_number is None else err_number))
+    listed = lambda order: ', '.join(c[1] for c in order)
+    if err_file is None:
+        chosen = by_file
+        if by_number is None:
+            warnings.warn('%s: conv layer names carry no usable numbering; trusting the file\'s layer_names order: %s'
+                          % (path, listed(chosen)), RuntimeWarning, stacklevel=4)
+        elif err_number is None and [c[1] for c in by_number] != [c[1] for c in by_file]:
+            warnings.warn('%s: layer_names order (%s) differs from the layers\' numbering (%s) and both fit the architecture; '
+                          'using layer_names order like keras\' load_weights' % (path, listed(by_file), listed(by_number)),
+                          RuntimeWarning, stacklevel=4)
+    else:
+        chosen = by_number
     for _, _, k, b in chosen:
         parts += [k.astype(np.float32).ravel(), b.astype(np.float32)]
     return np.concatenate(parts)

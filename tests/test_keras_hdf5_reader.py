@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def write_keras_like(path, cin, cout, d, f, flat, first_index=1, shuffle_names=False, bias_first=False, scope='',
-                     conv_name=None):
+                     conv_name=None, swap_body=False):
     from dsen2_amd import weights as W
     shapes = W.layer_shapes(cin, cout, d, f)
     names, off = [], 0
@@ -45,6 +45,9 @@ def write_keras_like(path, cin, cout, d, f, flat, first_index=1, shuffle_names=F
                 if li % 2 == 0:
                     add('add_%d' % ci)
         add('add_final')
+        if swap_body:                                # two body convolutions trade places in layer_names: both orders chain
+            i, j = names.index(b'conv2d_%d' % (first_index + 1)), names.index(b'conv2d_%d' % (first_index + 2))
+            names[i], names[j] = names[j], names[i]
         if shuffle_names:
             names = [names[i] for i in np.random.default_rng(0).permutation(len(names))]
         root.attrs['layer_names'] = names
@@ -180,3 +183,22 @@ def test_own_reader_and_h5py_agree_and_the_own_reader_is_the_one_used(tmp_path, 
         _same_tree(mine, theirs)
     monkeypatch.setattr(h5py, 'File', lambda *a, **k: (_ for _ in ()).throw(AssertionError('h5py used')))
     assert np.array_equal(W.load_flat(p, 10, 6, 6, 128), flat)
+
+
+def test_when_numbering_and_layer_names_order_both_fit_but_differ_keras_order_wins_loudly(tmp_path):
+    """keras' load_weights (testing/supres.py:63) pairs weighted layers in the FILE's layer_names order; a file whose body
+    layers are listed in another order than their numbering fits the architecture either way — the loader does what keras
+    would and names both orders in a warning instead of choosing silently."""
+    import warnings
+    from dsen2_amd import weights as W
+    flat = W.random_he_uniform(10, 6, 2, 128, seed=9, bias_scale=0.1)
+    p = str(tmp_path / 'swapped.hdf5')
+    write_keras_like(p, 10, 6, 2, 128, flat, swap_body=True)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        got = W.load_flat(p, 10, 6, 2, 128)
+    assert any('differs from the layers\' numbering' in str(w.message) for w in caught), [str(w.message) for w in caught]
+    n0, nb = 9 * 10 * 128 + 128, 9 * 128 * 128 + 128
+    a, b = flat[n0:n0 + nb], flat[n0 + nb:n0 + 2 * nb]
+    assert np.array_equal(got[:n0], flat[:n0]) and np.array_equal(got[n0:n0 + nb], b) and np.array_equal(got[n0 + nb:n0 + 2 * nb], a)
+    assert np.array_equal(got[n0 + 2 * nb:], flat[n0 + 2 * nb:])
