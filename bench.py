@@ -227,14 +227,14 @@ def main():
         # HBM traffic of that kernel: PMC counters cannot be read in-process, so this is the committed profile of this
         # config (tools/profile_round.sh -> tools/update_traffic_json.py) — quoted only while the instruction stream it was
         # measured on is the one this library was built from (dsen2_amd/kernel_isa.json, written by the build)
-        traffic, traffic_src = None, 'no committed PMC profile of this config'
+        traffic, traffic_src, tdat_ok = None, 'no committed PMC profile of this config', None
         tj = os.path.join(ROOT, 'profiles', 'body_conv_traffic.json')
         ij = os.path.join(ROOT, 'dsen2_amd', 'kernel_isa.json')
         if os.path.exists(tj) and args.batch == BATCH:
             tdat = json.load(open(tj)).get(args.config)
             built = json.load(open(ij)).get(args.config, {}).get('isa_sha256') if os.path.exists(ij) else None
             if tdat and built and tdat.get('isa_sha256') == built:
-                traffic, traffic_src = tdat['traffic_bytes'], tdat['source']
+                traffic, traffic_src, tdat_ok = tdat['traffic_bytes'], tdat['source'], tdat
             elif tdat:
                 traffic_src = 'STALE, not quoted: profiles/body_conv_traffic.json was measured on kernel ISA %s, this build is %s' % (
                     str(tdat.get('isa_sha256'))[:12], str(built)[:12])
@@ -244,6 +244,13 @@ def main():
                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK, 4), 'traffic': traffic,
                               'traffic_unit': 'bytes/launch (PMC, separate rocprofv3 passes; see traffic_source)',
                               'traffic_source': traffic_src,
+                              # north_star: "rocprof-reported MFMA utilisation and HBM GB/s against gfx950 peak" — the PMC traffic over
+                              # THIS run's launch duration against HBM3E's 8 TB/s, and the matrix pipes' busy fraction from the same
+                              # committed PMC passes (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs))
+                              'hbm_gbps': round(traffic / (ms * per_launch * 1e-3) / 1e9, 1) if traffic else None,
+                              'hbm_frac_of_8TBps': round(traffic / (ms * per_launch * 1e-3) / 8e12, 4) if traffic else None,
+                              'algorithmic_bytes': tdat_ok.get('algorithmic_bytes') if tdat_ok else None,
+                              'mfma_busy_pmc': tdat_ok.get('mfma_busy') if tdat_ok else None,
                               'kernel': '%s (3x3x%dx%d, %s, persistent%s)' % (
                                   ('conv3x3_body16w_x3_chain_kernel' if launches == 1 else 'conv3x3_body16w_x3_kernel') if x3 else ('conv3x3_body16w_chain_kernel' if launches == 1 else 'conv3x3_body16w_kernel') if bf else 'conv3x3_body32_kernel',
                                   FEAT, FEAT, 'three bf16 MFMA 16x16x32 per product (hi*hi + hi*lo + lo*hi), LDS-DMA staging, 16x32-pixel items' if x3

@@ -59,6 +59,11 @@ def main():
                  'fetch_size_kib': fetch_kib, 'write_size_kib': write_kib,
                  'read_bytes_corrected': read_b, 'write_bytes': write_b, 'traffic_bytes': read_b + write_b,
                  'algorithmic_bytes': algorithmic, 'dispatches': int(row['dispatches']), 'source': note}
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in row and 'GRBM_GUI_ACTIVE' in row:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (MI355X_MICROARCH.md, SQ PMC
+        # units): busy fraction of the matrix pipes = MFMA_BUSY / (1024 x GRBM / 8)
+        data[cfg]['mfma_busy'] = round(float(row['SQ_VALU_MFMA_BUSY_CYCLES']) / (128.0 * float(row['GRBM_GUI_ACTIVE'])), 4)
+        data[cfg]['gui_active_cycles_per_xcd'] = float(row['GRBM_GUI_ACTIVE']) / 8.0
     with open(dst or path, 'w') as f:
         json.dump(data, f, indent=1)
         f.write('\n')
