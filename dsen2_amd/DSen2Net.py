@@ -57,7 +57,7 @@ class S2Model(object):
         # several, must not share the activation buffers the kernels of both would be writing.
         self._workspaces = {}
         self._ws_lock = threading.Lock()
-        self.max_workspace_bytes = 6 << 30   # predict() sizes its internal batches to stay below this
+        self.max_workspace_bytes = 6 << 30   # predict() and the tile path size their batches to stay below this
 
     # -- keras.Model surface -------------------------------------------------------------------
     def count_params(self):
@@ -169,6 +169,23 @@ class S2Model(object):
         per = self.workspace_bytes(1, h, w)
         return max(1, int(self.max_workspace_bytes // per))
 
+    def preferred_batch(self, h, w):
+        """The batch the tile path and predict() cut their work into: batch_limit() for fp32 and for large patches; in the
+        bf16 modes, for patches the chain kernel takes (up to 64 x 64: there it is 1-3 % ahead of the per-layer launches and
+        bit-identical to them; profiles/r04_k_chain_vs_layerwise.txt), the largest batch below the limit that runs ALL
+        residual-block convolutions in one chain launch (body_launches() == 1: a multiple of the CU count).  Results never
+        depend on the batch size."""
+        limit = self.batch_limit(h, w)
+        if self.precision == 'fp32' or self.num_layers <= 0:
+            return limit
+        cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        n = (limit // cus) * cus
+        while n >= cus:
+            if self.body_launches(n, h, w) == 1:
+                return n
+            n -= cus
+        return limit
+
     def predict(self, x, batch_size=None, verbose=0):
         """keras Model.predict: list of NCHW float32 ndarrays -> ndarray [N, cout, H, W].
 
@@ -185,7 +202,7 @@ class S2Model(object):
         for a, c in zip(xs, self.bands):
             if a.shape != (n, c, h, w):
                 raise ValueError('input of shape %r where %r is expected' % (a.shape, (n, c, h, w)))
-        bs = self.batch_limit(h, w) if batch_size is None else int(batch_size)
+        bs = self.preferred_batch(h, w) if batch_size is None else int(batch_size)
         out = np.empty((n, self.cout, h, w), np.float32)
         if n == 0:
             return self._progress_end(verbose, out)

@@ -882,8 +882,16 @@ static hipError_t launch_body16w_chain_one(ConvParams p, ChainArgs c, hipStream_
 
 // Whole patches per workgroup for the chain kernel, or 0 when a chain would leave CUs idle that the per-layer kernels
 // use: the chain hands out images, the per-layer launch items; chain only if it needs no more item rounds per layer.
+// ... and only for patches of at most 8 tiles (64 x 64): measured (tools/chain_vs_layerwise_probe.py,
+// profiles/r04_k_chain_vs_layerwise.txt) the chain is 1-3 % ahead of the per-layer launches up to there and 1-5 % BEHIND them
+// at 96^2 (F = 256), 128^2 and 192^2 patches in every mode — with 32+ items per patch and layer the launch boundaries it
+// removes are a per-mille of the layer's time, and a workgroup walking its own patches alone loses the L2 sharing of halo
+// rows that neighbouring workgroups get when a layer's items are handed out in order.
+constexpr int kChainMaxTilesPerPatch = 8;
+
 int body16w_chain_patches_per_wg(int n, int h, int w, int feat, int cus) {
   if (n <= 0 || cus <= 0) return 0;
+  if ((long long)((w + TW - 1) / TW) * ((h + TH - 1) / TH) > kChainMaxTilesPerPatch) return 0;
   const long long ipp = (long long)((w + TW - 1) / TW) * ((h + TH - 1) / TH) * (feat / 128);    // items per patch
   const int ppw = (n + cus - 1) / cus;
   const long long rounds_layerwise = (n * ipp + cus - 1) / cus;

@@ -140,7 +140,7 @@ def _run(dsets, scales, patch, border, deep, run_60):
             shifted = (my_org * s).astype(np.int32)
             shifted[:, 0] -= r0
             org_dev.append(torch.from_numpy(np.ascontiguousarray(shifted)).to(dev))      # uploaded once: the loop only enqueues
-        bs = model.batch_limit(patch, patch)
+        bs = model.preferred_batch(patch, patch)
         # One rank, a large image: rows that are final are recomposed right after the batch that completes them — rows below
         # min(t * inner, H - inner) once the first t tile rows of patches are done (the last `inner` rows belong to the clamped
         # last tile row, patches.py:396-401) — and an event marks each band, so that the download can later run band by band

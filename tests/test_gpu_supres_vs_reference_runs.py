@@ -30,7 +30,7 @@ class StandInModel(object):
     def load_weights(self, path):
         self.seen['load_weights'] = path
 
-    def batch_limit(self, h, w):
+    def preferred_batch(self, h, w):
         return 3                                   # several batches per call: results must not depend on it
 
     def forward_device(self, xs, out=None):

@@ -32,6 +32,7 @@ ap.add_argument('--check', action='store_true', help='multi-rank: also verify th
 ap.add_argument('--precision', default=None, choices=['fp32', 'bf16', 'bf16x3'], help="supres.PRECISION (default: DSEN2_PRECISION or fp32)")
 ap.add_argument('--deep', action='store_true', help='VDSen2 (d=32, F=256) instead of DSen2')
 ap.add_argument('--lazy', type=int, default=-1, metavar='MARGIN', help='hand the images over as cli.LazyRows (rows read on demand, as the GDAL branch of the command line does under torch.distributed) with this margin of 10 m rows; reports the largest share of rows a rank read')
+ap.add_argument('--plain-batches', action='store_true', help='A/B: cut the patches into memory-bound batches (batch_limit) instead of preferred_batch (bf16 modes: multiples of the CU count, which run the one-launch chain)')
 ap.add_argument('--port', type=int, default=0, help=argparse.SUPPRESS)
 args = ap.parse_args()
 
@@ -40,6 +41,9 @@ from dsen2_amd import dist          # noqa: E402
 rank, world, _ = dist.init_from_env(args.backend)       # LOCAL_RANK's GPU, dmabuf-IPC environment, process group
 if args.precision:
     supres.PRECISION = args.precision
+if args.plain_batches:
+    from dsen2_amd.DSen2Net import S2Model
+    S2Model.preferred_batch = S2Model.batch_limit
 
 n = args.size - args.size % 6
 rng = np.random.default_rng(0)
@@ -66,7 +70,7 @@ else:
     np.save(os.path.join(tmp, 's2_032_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 6, 128, seed=11))
     np.save(os.path.join(tmp, 's2_030_lr_1e-05.npy'), weights.random_he_uniform(12, 2, 6, 128, seed=12))
 supres.MDL_PATH = os.path.join(tmp, '')
-out = {'tile': [n, n], 'data': 'synthetic', 'n_gpus': world, 'precision': supres.PRECISION, 'deep': bool(args.deep), 'patches20': int(np.ceil(n / 112.0) ** 2), 'patches60': int(np.ceil(n / 168.0) ** 2)}
+out = {'tile': [n, n], 'data': 'synthetic', 'n_gpus': world, 'precision': supres.PRECISION, 'batches': 'batch_limit' if args.plain_batches else 'preferred_batch', 'deep': bool(args.deep), 'patches20': int(np.ceil(n / 112.0) ** 2), 'patches60': int(np.ceil(n / 168.0) ** 2)}
 
 
 def timed(fn, *a):

@@ -22,7 +22,7 @@ x10u = torch.from_numpy(d10.view(np.int16)).to(dev); t2b = T(); out['h2d_uint16_
 org, n_alloc = P.tile_origins(x20.shape, 64, 4); used = org.shape[0]
 with contextlib.redirect_stdout(io.StringIO()):
     model = supres._get_model(((4, None, None), (6, None, None)), False, False)
-bs = model.batch_limit(128, 128)
+bs = model.preferred_batch(128, 128)
 pred = torch.empty((used, 6, 128, 128), device=dev)
 tg = tu = tf = 0.0
 for i0 in range(0, used, bs):

@@ -65,7 +65,7 @@ out['n1_measured_s'] = round(t1 - t0, 3)
 del y
 
 # ---- rank 0's shard at each N: slab conversion + upload, GPU work on its patches, crop into the send buffer ----
-bs = model.batch_limit(patch, patch)
+bs = model.preferred_batch(patch, patch)
 per_n = {}
 for world in (1, 2, 4, 8):
     per = D.per_rank(used, world)
