@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU work for cpu_baseline')
+    ap.add_argument('--roofline-seconds', type=float, default=5.0, help='GPU time of the instrumented passes behind `roofline`, and again of their event-free replay: ~10 s of uninterrupted GPU work at the default, long enough for an outside utilisation sampler to see the card busy (the timed loop itself is 0.26 s); 1.5 s gives the same numbers (profiles/r04_ablation.md §5)')
     ap.add_argument('--no-gather', action='store_true', help='skip the per-step output all-gather (N>1)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices; '
@@ -195,8 +196,8 @@ def main():
         #     convolutions, output convolution — consecutive intervals between the same time stamps, so
         #     launches x ms_per_launch + first_ms + out_ms = forward_ms by construction
         #     (3 plain passes are enqueued right before them, no synchronisation in between: the GPU is at its steady clock)
-        # at least `steps` instrumented passes, up to 100 while they stay within ~1.5 s (1.3 s at the default config): a stable mean
-        n_prof = max(args.steps, min(100, int(1500.0 / max(ms_per_step, 1e-3))))
+        # at least `steps` instrumented passes, as many as fit --roofline-seconds (5 s: ~390 at the default config): a stable mean
+        n_prof = max(args.steps, min(int(100 * args.roofline_seconds / 1.5), int(1e3 * args.roofline_seconds / max(ms_per_step, 1e-3))))
         prof = model.profile_forward(xs, out=outs[0], iters=n_prof, warm=3)
         ms = prof['body_ms'] / (2 * NUM_LAYERS)
         # (1b) the same passes WITHOUT the events inside them, right after and equally warm (the kernels run on torch's
