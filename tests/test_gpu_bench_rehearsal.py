@@ -23,7 +23,7 @@ def _free_port():
 def test_bench_two_ranks_gloo_rehearsal():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', _free_port(), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
-           '--warmup', '1', '--batch', '64', '--backend', 'gloo']
+           '--warmup', '1', '--batch', '64', '--backend', 'gloo', '--roofline-seconds', '0.5']
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
@@ -34,7 +34,7 @@ def test_bench_two_ranks_gloo_rehearsal():
 
 
 def test_bench_single_gpu_line_has_contract_fields():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-budget', '2'],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-budget', '2', '--roofline-seconds', '0.5'],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
@@ -50,7 +50,7 @@ def test_bench_line_closes_on_itself_and_other_configs_run():
     traffic figure is quoted only with the ISA hash of this build; the bf16x3 config reports dtype "bf16x3" against the bf16
     peak with three MFMAs per product and never claims the headline metric."""
     def line(*extra):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline'] + list(extra),
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline', '--roofline-seconds', '0.5'] + list(extra),
                            capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-2000:]
         return json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
@@ -172,7 +172,7 @@ def test_cli_two_ranks_gloo_writes_the_single_rank_file_from_rank_0_only(tmp_pat
                             capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
     assert single.returncode == 0, single.stderr[-2000:]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', _free_port(), '-m', 'dsen2_amd.cli', inp, str(tmp_path / 'two.npz'), '--backend', 'gloo'] + common
+           '--master-port', _free_port(), '-m', 'dsen2_amd.cli', inp, str(tmp_path / 'two.npz'), '--backend', 'gloo', '--roofline-seconds', '0.5'] + common
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     # one rank talked: every line of the single-process run appears exactly once
