@@ -172,7 +172,7 @@ def test_cli_two_ranks_gloo_writes_the_single_rank_file_from_rank_0_only(tmp_pat
                             capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
     assert single.returncode == 0, single.stderr[-2000:]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', _free_port(), '-m', 'dsen2_amd.cli', inp, str(tmp_path / 'two.npz'), '--backend', 'gloo', '--roofline-seconds', '0.5'] + common
+           '--master-port', _free_port(), '-m', 'dsen2_amd.cli', inp, str(tmp_path / 'two.npz'), '--backend', 'gloo'] + common
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     # one rank talked: every line of the single-process run appears exactly once
