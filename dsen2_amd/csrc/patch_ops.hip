@@ -51,7 +51,13 @@ hipError_t launch_pack_inputs(const float* x10, const float* x20, const float* x
 //   src = scale*dst + offset with scale = in/out, offset = 0.5*scale - 0.5, evaluated in float32 with a
 //   separate multiply and add exactly as skimage 0.18.3 does (warp() casts its matrix to the image dtype);
 //   neighbours floor(src)/ceil(src), folded back by mirroring WITHOUT repeating the edge sample;
-//   the blend itself is done in float64 and rounded once to float32.
+//   the blend follows skimage's compiled `bilinear_interpolation` for a float32 image operation by operation:
+//     top = (1.0 - double(dc)) * double(left) + double(float32(dc * right))      (`dc * right`: both float32 in the Cython
+//     source, so that product alone is a float32 multiply; the literal 1 promotes everything else to double)
+//     out = float32((1.0 - double(dr)) * top + double(dr) * bottom)
+//   — the captured outputs of the reference's interp_patches are reproduced BIT FOR BIT (tests/test_gpu_patches.py).  warp()'s
+//   clip to the input's [min, max] is a no-op for this arithmetic (a plateau of equal taps returns its value exactly, every
+//   operation is monotone in the taps; the tests' CPU restatement keeps the clip and agrees) and is not computed.
 __device__ __forceinline__ int mirror_index(int i, int dim) {
   if (dim == 1) return 0;
   const int cmax = dim - 1;
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     // column taps of the four outputs (identical for every row)
     int c0[4], c1[4];
     double dc[4];
+    float dcf[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int oj = oj0 + e < ow ? oj0 + e : ow - 1;
@@ -102,7 +109,8 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
       const float cf = floorf(c);
       c0[e] = mirror_index((int)cf, w);
       c1[e] = mirror_index((int)ceilf(c), w);
-      dc[e] = (double)__fsub_rn(c, cf);
+      dcf[e] = __fsub_rn(c, cf);
+      dc[e] = (double)dcf[e];
     }
     // horizontal blend of input row r at the four output columns
     auto hrow = [&](int r, double (&H)[4]) {
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         else if (c1[e] == pc0) q1 = pq0;
         else q1 = (double)__fdiv_rn(src[c1[e]], 30000.0f);
         pc0 = c0[e]; pc1 = c1[e]; pq0 = q0; pq1 = q1;
-        H[e] = (1.0 - dc[e]) * q0 + dc[e] * q1;
+        H[e] = (1.0 - dc[e]) * q0 + (double)__fmul_rn(dcf[e], (float)q1);      // (q1 is a float32 quotient: the cast is exact)
       }
     };
     int ia = -1, ib = -1;                       // input rows held in Ha / Hb
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
 // behind a branch, so a thread's ~20 loads are issued one after the other and it waits for each.  Here a thread's four output
 // columns read from a window of 4 consecutive source columns (3 * sx + 1 < 4 for sx <= 1/2) and its eight output rows from NR
 // consecutive source rows (7 * sy + 2 <= NR): all NR x 4 samples are loaded at once, divided, blended horizontally
-// (operands picked by index selects, the same two products and one sum per output column as above) and parked in LDS
+// (operands picked by index selects, the same two products — one double, one float32 — and one sum per output column as above) and parked in LDS
 // ([row][column][thread]: a thread only ever reads its own values, no barrier); the vertical blend then indexes LDS by row.
 // Same operations on the same values as upsample_kernel: bit-identical (tests/test_gpu_patches.py against
 // dsen2_upsample_mirror_bilinear_ref; tools/ab_upsample_bits.py against the previous library), 1.3-1.4x faster.
@@ -188,6 +196,7 @@ __global__ __launch_bounds__(256) void upsample_window_kernel(const float* __res
     // columns: the window starts at the first output's left tap
     int i0[4], i1[4];
     double dc[4];
+    float dcf[4];
     int cb = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -197,7 +206,8 @@ __global__ __launch_bounds__(256) void upsample_window_kernel(const float* __res
       if (e == 0) cb = (int)cf;
       i0[e] = (int)cf - cb;
       i1[e] = (int)ceilf(c) - cb;
-      dc[e] = (double)__fsub_rn(c, cf);
+      dcf[e] = __fsub_rn(c, cf);
+      dc[e] = (double)dcf[e];
     }
     int wcol[4];
 #pragma unroll
@@ -224,8 +234,8 @@ __global__ __launch_bounds__(256) void upsample_window_kernel(const float* __res
     for (int j = 0; j < NR; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const double q0 = (double)pick(q[j], i0[e]), q1 = (double)pick(q[j], i1[e]);
-        h_s[(j * 4 + e) * 256 + tid] = (1.0 - dc[e]) * q0 + dc[e] * q1;
+        const double q0 = (double)pick(q[j], i0[e]);
+        h_s[(j * 4 + e) * 256 + tid] = (1.0 - dc[e]) * q0 + (double)__fmul_rn(dcf[e], pick(q[j], i1[e]));
       }
 #pragma unroll
     for (int k = 0; k < kUpRows; ++k) {

@@ -9,8 +9,8 @@ Restates (paths relative to /root/reference):
 PARITY STATUS: pinned.  tests/golden/patches_*.npz hold outputs of the reference's own functions
 (imported from /root/reference under /opt/conda/bin/python3.9, scikit-image 0.18.3) produced by
 tests/golden/make_golden_patches.py; tests/test_oracle_patches.py checks this file against them
-(tiling / recompose bit-exact, up-sampling within a few float32 ulp — skimage interpolates with
-float32 coordinates, this restatement with float64).
+(tiling / recompose bit-exact; up-sampling BIT-EXACT too in the f32_coords=True mode, which follows scikit-image
+0.18.3's float32 arithmetic operation by operation — see interp_patches).
 
 Third-party arithmetic: scikit-image ``transform.resize`` (unpinned in the reference's README;
 0.18.3 is what the capture used): order-1 interpolation at half-pixel centres
@@ -55,22 +55,44 @@ def _axis_taps(n_in, n_out, f32_coords=False):
 def interp_patches(image_lr, hr_shape, f32_coords=False):
     """[N,C,h,w] float32 -> [N,C,H,W] float32 (patches.py:11-16). hr_shape = 4-tuple, H,W read from [2:4].
 
-    f32_coords=False: exact (float64) sample positions — the mathematical definition.
-    f32_coords=True : emulate skimage 0.18.3's float32 sample positions (agrees with the captured
-                      reference outputs to ~1 float32 ulp; the exact mode differs by up to ~3e-6
-                      relative at x6 because 1/6 is not representable).
+    f32_coords=False: exact (float64) sample positions and blend — the mathematical definition.
+    f32_coords=True : scikit-image 0.18.3's arithmetic for a float32 image, operation by operation — BIT-IDENTICAL to the
+                      captured reference outputs (tests/test_oracle_patches.py).  What `resize` -> `warp` -> `_warp_fast[float32]`
+                      -> `bilinear_interpolation` computes there (established from the compiled extension's instruction
+                      sequence and confirmed bit for bit on random images, tests/golden/make_golden_patches.py's captures):
+                        c, r   = float32(scale) * float32(index) + float32(offset), each operation rounded to float32
+                        dc, dr = c - floor(c), r - floor(r) in float32
+                        top    = (1.0 - double(dc)) * double(top_left) + double(float32(dc * top_right))
+                        bottom = (1.0 - double(dc)) * double(bottom_left) + double(float32(dc * bottom_right))
+                        out    = float32((1.0 - double(dr)) * top + double(dr) * bottom)
+                      — the `dc * neighbour` product alone is a float32 multiply (both operands are float32 in the Cython
+                      source), everything else is promoted to double by the literal 1.  `warp` then clips to the input's
+                      [min, max]: a no-op for this arithmetic (a plateau of equal taps returns its value exactly — the blend's
+                      error stays below half a float32 ulp — and every operation is monotone in the taps), kept for fidelity.
     """
     image_lr = np.asarray(image_lr, np.float32)
     oh, ow = int(hr_shape[2]), int(hr_shape[3])
     h, w = image_lr.shape[2:4]
     r0, r1, fr = _axis_taps(h, oh, f32_coords)
     c0, c1, fc = _axis_taps(w, ow, f32_coords)
-    x = (image_lr / np.float32(30000)).astype(np.float64)       # float32 divide, as patches.py:15
-    fc = fc[None, None, None, :]
-    fr = fr[None, None, :, None]
-    top = (1 - fc) * x[:, :, r0][:, :, :, c0] + fc * x[:, :, r0][:, :, :, c1]
-    bot = (1 - fc) * x[:, :, r1][:, :, :, c0] + fc * x[:, :, r1][:, :, :, c1]
-    out = ((1 - fr) * top + fr * bot).astype(np.float32)
+    xq = image_lr / np.float32(30000)                              # float32 divide, as patches.py:15
+    x = xq.astype(np.float64)
+    fcb = fc[None, None, None, :]
+    frb = fr[None, None, :, None]
+    if f32_coords:
+        dcf = fc.astype(np.float32)[None, None, None, :]
+        right_top = (dcf * xq[:, :, r0][:, :, :, c1]).astype(np.float32).astype(np.float64)
+        right_bot = (dcf * xq[:, :, r1][:, :, :, c1]).astype(np.float32).astype(np.float64)
+        top = (1.0 - fcb) * x[:, :, r0][:, :, :, c0] + right_top
+        bot = (1.0 - fcb) * x[:, :, r1][:, :, :, c0] + right_bot
+        out = ((1.0 - frb) * top + frb * bot).astype(np.float32)
+        lo = xq.min(axis=(2, 3), keepdims=True)
+        hi = xq.max(axis=(2, 3), keepdims=True)
+        out = np.clip(out, lo, hi)                                 # warp(clip=True): skimage/transform/_warps.py
+    else:
+        top = (1 - fcb) * x[:, :, r0][:, :, :, c0] + fcb * x[:, :, r0][:, :, :, c1]
+        bot = (1 - fcb) * x[:, :, r1][:, :, :, c0] + fcb * x[:, :, r1][:, :, :, c1]
+        out = ((1 - frb) * top + frb * bot).astype(np.float32)
     return out * np.float32(30000)                                # float32 multiply, as patches.py:15
 
 

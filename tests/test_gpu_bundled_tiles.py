@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 from oracle import dsen2_oracle as do
 
 TILES = ['tile_T33UUB_600.npz', 'tile_T49JGM_600.npz']
-TIGHT = dict(rtol=4e-7, atol=2e-3)          # tests/test_gpu_patches.py: a few float32 ulp of the captured reference output
+from bits import assert_same_bits          # noqa: E402  (the up-sampler reproduces the reference's captured bits)
 SUB = (slice(None), slice(None), slice(3, None, 7), slice(2, None, 5))
 RMSE_GATE_NORMALISED = 1e-4                 # BASELINE.md §2 (fp32, normalised domain)
 
@@ -57,16 +57,16 @@ def test_tiling_of_the_whole_bundled_tile_equals_the_reference_capture(golden_di
     assert p10.shape == (36, 4, 128, 128) and p20.shape == (36, 6, 128, 128) and int(g['n20']) == 36
     np.testing.assert_array_equal(sums(p10), g['p10_sum'])
     assert np.array_equal(p10[-1], g['p10_last'])                        # the clamped last patch, bit for bit
-    np.testing.assert_allclose(p20[SUB], g['p20_sub'], **TIGHT)
-    np.testing.assert_allclose(p20[-1], g['p20_last'], **TIGHT)
+    assert_same_bits(p20[SUB], g['p20_sub'])
+    assert_same_bits(p20[-1], g['p20_last'])
     np.testing.assert_allclose(sums(p20), g['p20_sum'], rtol=1e-6)
     q10, q20, q60 = gp.get_test_patches60(*d, patchSize=192, border=12)
     assert q10.shape == (16, 4, 192, 192) and q60.shape == (16, 2, 192, 192) and int(g['n60']) == 16
     np.testing.assert_array_equal(sums(q10), g['q10_sum'])
-    np.testing.assert_allclose(q20[SUB], g['q20_sub'], **TIGHT)
-    np.testing.assert_allclose(q60[SUB], g['q60_sub'], **TIGHT)
-    np.testing.assert_allclose(q20[-1, :2], g['q20_last'], **TIGHT)
-    np.testing.assert_allclose(q60[-1], g['q60_last'], **TIGHT)
+    assert_same_bits(q20[SUB], g['q20_sub'])
+    assert_same_bits(q60[SUB], g['q60_sub'])
+    assert_same_bits(q20[-1, :2], g['q20_last'])
+    assert_same_bits(q60[-1], g['q60_last'])
     np.testing.assert_allclose(sums(q60), g['q60_sum'], rtol=1e-6)
     # recompose_images: the 10 m patches give the tile back exactly (both geometries); the up-sampled patches give
     # the image the reference's recompose_images gave
@@ -74,11 +74,11 @@ def test_tiling_of_the_whole_bundled_tile_equals_the_reference_capture(golden_di
     assert np.array_equal(quiet(gp.recompose_images, q10, border=12, size=d[0].shape), d[0])
     rec20 = quiet(gp.recompose_images, p20, border=8, size=d[0].shape)
     assert rec20.shape == (600, 600, 6) and rec20.dtype == np.float32
-    np.testing.assert_allclose(rec20[1::5, 2::7], g['rec20_sub'], **TIGHT)
+    assert_same_bits(rec20[1::5, 2::7], g['rec20_sub'])
     np.testing.assert_allclose(rec20.astype(np.float64).sum(axis=1), g['rec20_rows'], rtol=1e-6)
     np.testing.assert_allclose(rec20.astype(np.float64).sum(axis=0), g['rec20_cols'], rtol=1e-6)
     rec60 = quiet(gp.recompose_images, q60, border=12, size=d[0].shape)
-    np.testing.assert_allclose(rec60[1::5, 2::7], g['rec60_sub'], **TIGHT)
+    assert_same_bits(rec60[1::5, 2::7], g['rec60_sub'])
     np.testing.assert_allclose(rec60.astype(np.float64).sum(axis=1), g['rec60_rows'], rtol=1e-6)
     np.testing.assert_allclose(rec60.astype(np.float64).sum(axis=0), g['rec60_cols'], rtol=1e-6)
 

@@ -12,16 +12,18 @@ from oracle import patches_oracle as po
 CASES20 = ['patches_20_div.npz', 'patches_20_nondiv.npz', 'patches_20_b8.npz']
 CASES60 = ['patches_60_div.npz', 'patches_60_nondiv.npz', 'patches_60_b12.npz']
 
-# skimage 0.18.3 interpolates with float32 sample coordinates.  Two checks:
-#  * oracle in f32-coordinate mode vs reference: a few float32 ulp (values <= 13110 -> ulp <= 9.8e-4);
-#  * oracle in exact-coordinate mode vs reference: coordinate error <= ~2e-6 of a pixel times the local
+# Two checks of the up-sampler against the captured outputs of the reference's interp_patches (scikit-image 0.18.3):
+#  * the oracle's f32_coords mode restates skimage's float32 arithmetic operation by operation: BIT-IDENTICAL;
+#  * the exact-coordinate mode (the mathematical definition): coordinate error <= ~2e-6 of a pixel times the local
 #    gradient (<= 13110 / pixel) -> 0.03 raw reflectance units = 1.5e-5 after /2000 (gate: 1e-4 RMSE).
-TIGHT = dict(rtol=4e-7, atol=2e-3)
 LOOSE = dict(rtol=0, atol=3e-2)
 
 
+from bits import assert_same_bits      # noqa: E402
+
+
 def check_interp(fn, expect, err_msg=''):
-    np.testing.assert_allclose(fn(True), expect, err_msg=err_msg + ' (f32 coords)', **TIGHT)
+    assert_same_bits(fn(True), expect, err_msg + ' (skimage arithmetic)')
     np.testing.assert_allclose(fn(False), expect, err_msg=err_msg + ' (exact coords)', **LOOSE)
 
 
@@ -121,15 +123,15 @@ def test_real_tile_crop_default_geometry(golden_dir):
     assert p10.shape[0] == int(g['n20']) == 9
     np.testing.assert_array_equal(p10.astype(np.float64).sum(axis=(2, 3)), g['p10_sum'])
     sub = (slice(None), slice(None), slice(3, None, 7), slice(2, None, 5))
-    np.testing.assert_allclose(p20[sub], g['p20_sub'], **TIGHT)
-    np.testing.assert_allclose(p20[4, :2], g['p20_patch4'], **TIGHT)
+    assert_same_bits(p20[sub], g['p20_sub'])
+    assert_same_bits(p20[4, :2], g['p20_patch4'])
     np.testing.assert_allclose(p20.astype(np.float64).sum(axis=(2, 3)), g['p20_sum'], rtol=1e-6)
     q10, q20, q60 = po.get_test_patches60(*d, patchSize=192, border=12, f32_coords=True)
     assert q10.shape[0] == int(g['n60']) == 4
     np.testing.assert_array_equal(q10.astype(np.float64).sum(axis=(2, 3)), g['q10_sum'])
-    np.testing.assert_allclose(q20[sub], g['q20_sub'], **TIGHT)
-    np.testing.assert_allclose(q60[sub], g['q60_sub'], **TIGHT)
-    np.testing.assert_allclose(q60[0, :1], g['q60_patch0'], **TIGHT)
+    assert_same_bits(q20[sub], g['q20_sub'])
+    assert_same_bits(q60[sub], g['q60_sub'])
+    assert_same_bits(q60[0, :1], g['q60_patch0'])
     # round trip on the real data
     rec = quiet(po.recompose_images, p10, border=8, size=d[0].shape)
     assert np.array_equal(rec, d[0])
@@ -148,23 +150,23 @@ def test_whole_bundled_tiles(golden_dir, name):
     assert p10.shape[0] == int(g['n20']) == 36
     np.testing.assert_array_equal(sums(p10), g['p10_sum'])
     assert np.array_equal(p10[-1], g['p10_last'])
-    np.testing.assert_allclose(p20[sub], g['p20_sub'], **TIGHT)
-    np.testing.assert_allclose(p20[-1], g['p20_last'], **TIGHT)
+    assert_same_bits(p20[sub], g['p20_sub'])
+    assert_same_bits(p20[-1], g['p20_last'])
     np.testing.assert_allclose(sums(p20), g['p20_sum'], rtol=1e-6)
     q10, q20, q60 = po.get_test_patches60(*d, patchSize=192, border=12, f32_coords=True)
     assert q10.shape[0] == int(g['n60']) == 16
     np.testing.assert_array_equal(sums(q10), g['q10_sum'])
-    np.testing.assert_allclose(q20[sub], g['q20_sub'], **TIGHT)
-    np.testing.assert_allclose(q60[sub], g['q60_sub'], **TIGHT)
-    np.testing.assert_allclose(q20[-1, :2], g['q20_last'], **TIGHT)
-    np.testing.assert_allclose(q60[-1], g['q60_last'], **TIGHT)
+    assert_same_bits(q20[sub], g['q20_sub'])
+    assert_same_bits(q60[sub], g['q60_sub'])
+    assert_same_bits(q20[-1, :2], g['q20_last'])
+    assert_same_bits(q60[-1], g['q60_last'])
     assert np.array_equal(quiet(po.recompose_images, p10, border=8, size=d[0].shape), d[0])
     assert np.array_equal(quiet(po.recompose_images, q10, border=12, size=d[0].shape), d[0])
     rec20 = quiet(po.recompose_images, p20, border=8, size=d[0].shape)
-    np.testing.assert_allclose(rec20[1::5, 2::7], g['rec20_sub'], **TIGHT)
+    assert_same_bits(rec20[1::5, 2::7], g['rec20_sub'])
     np.testing.assert_allclose(rec20.astype(np.float64).sum(axis=1), g['rec20_rows'], rtol=1e-6)
     rec60 = quiet(po.recompose_images, q60, border=12, size=d[0].shape)
-    np.testing.assert_allclose(rec60[1::5, 2::7], g['rec60_sub'], **TIGHT)
+    assert_same_bits(rec60[1::5, 2::7], g['rec60_sub'])
     np.testing.assert_allclose(rec60.astype(np.float64).sum(axis=0), g['rec60_cols'], rtol=1e-6)
 
 
