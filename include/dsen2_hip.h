@@ -182,7 +182,8 @@ int dsen2_model_time_body_conv(dsen2_model *m, int layer, const float *dev_in, c
 /* ---- tiling / up-sampling / recomposition (utils/patches.py) --------------------------------
  * dsen2_upsample_mirror_bilinear  <->  interp_patches            utils/patches.py:11-16
  *   planes x [h,w] -> planes x [oh,ow]; half-pixel-centre bilinear with mirror boundary (skimage
- *   resize mode='reflect'), including the /30000 .. *30000 round trip.  The result is then divided by
+ *   resize mode='reflect'), including the /30000 .. *30000 round trip — scikit-image 0.18.3's float32 arithmetic operation
+ *   by operation: the reference's outputs bit for bit.  The result is then divided by
  *   `post_divisor` (1.0 = exact no-op, 2000 folds `p20 /= SCALE`, testing/supres.py:24). */
 int dsen2_upsample_mirror_bilinear(const float *dev_in, float *dev_out, int planes, int h, int w, int oh,
                                    int ow, float post_divisor, void *stream);
