@@ -11,10 +11,15 @@ cross-correlation (no kernel flip), one pixel of zero padding, kernel stored HWI
 ``(3, 3, Cin, Cout)``, bias added before the activation, ``he_uniform`` = U(+-sqrt(6 / fan_in))
 with fan_in = 9 * Cin, bias initialised to zero.
 
-PARITY STATUS: **unpinned for the CNN graph** — keras/tensorflow are not installed in the build
+PARITY STATUS: **parity unpinned for the CNN's arithmetic** — keras/tensorflow are not installed in the build
 container and the trained checkpoints are stripped from the reference checkout, so no output of
-the reference network itself could be captured.  This restatement is cross-checked against an
-independent C implementation (oracle/dsen2_oracle.c) and against torch's conv2d in tests/.
+the reference network itself could be captured.  What IS pinned is the WIRING: tests/golden/graph_trace.json
+records what the reference's own utils/DSen2Net.py builds when it is executed (under a recording stand-in for
+the keras names it imports, tests/golden/make_golden_graph.py), and tests/test_oracle_graph_trace.py requires
+forward() below to equal that graph, evaluated with conv3x3 / ReLU / x 0.1 / add / concatenate, bit for bit —
+input order, fused ReLU of the first convolution, residual structure, block count, which input is added back,
+weight order.  What a keras Conv2D computes (next paragraph) remains a reading.  The restatement is also
+cross-checked against an independent C implementation (oracle/dsen2_oracle.c) and against torch's conv2d in tests/.
 
 Weight container ("keras flat" order) used by every implementation in this repo:
   [conv_in.kernel(3,3,Cin,F), conv_in.bias(F),
