@@ -234,3 +234,20 @@ def test_windowed_upsampler_gives_the_general_kernels_bits():
             a = P.interp_patches_device(x, (oh, ow), post_divisor=pd)
             b = P.interp_patches_device(x, (oh, ow), post_divisor=pd, ref=True)
             assert torch.equal(a, b), (n, c, h, w, oh, ow, pd)
+
+
+def test_interp_patches_bit_exact_beyond_the_tile_path_factors(golden_dir):
+    """The reference's interp_patches on non-integer factors, odd / tiny planes, plateaus at a plane's extremes, a constant plane
+    and values up to 65535 (tests/golden/interp_shapes.npz): the HIP up-sampler — the windowed kernel where the factor allows
+    it, the general one elsewhere, and the general one forced — gives the reference's bits."""
+    from dsen2_amd import patches as gp
+    g = load(golden_dir, 'interp_shapes.npz')
+    n = len([k for k in g.files if k.startswith('in_')])
+    assert n >= 12
+    for k in range(n):
+        x, want = g['in_%02d' % k], g['out_%02d' % k]
+        tag = 'case %d %r -> %r' % (k, x.shape[2:], want.shape[2:])
+        assert_same_bits(gp.interp_patches(x, want.shape), want, tag)
+        import torch
+        ref = gp.interp_patches_device(torch.from_numpy(x).cuda(), want.shape[2:], ref=True).cpu().numpy()
+        assert_same_bits(ref, want, tag + ' (general kernel)')

@@ -190,3 +190,17 @@ def test_a_patch_of_a_large_tile_is_a_patch_of_an_aligned_crop():
         c10, c20 = crop(r0)
         assert c10.shape[0] == 16
         assert np.array_equal(c10[pick], full10[idx]) and np.array_equal(c20[pick], full20[idx]), (r0, pick, idx)
+
+
+def test_interp_patches_bit_exact_beyond_the_tile_path_factors(golden_dir):
+    """tests/golden/interp_shapes.npz (make_golden_interp_shapes.py): the reference's interp_patches on non-integer factors, odd
+    / tiny planes, plateaus at a plane's extremes, a constant plane, values up to 65535 — the oracle's restatement of
+    scikit-image 0.18.3's float32 arithmetic gives the same bits, with and without warp()'s clip (a no-op for it)."""
+    g = load(golden_dir, 'interp_shapes.npz')
+    n = len([k for k in g.files if k.startswith('in_')])
+    assert n >= 12
+    for k in range(n):
+        x, want = g['in_%02d' % k], g['out_%02d' % k]
+        got = po.interp_patches(x, want.shape, f32_coords=True)
+        assert_same_bits(got, want, 'case %d %r -> %r' % (k, x.shape[2:], want.shape[2:]))
+        assert_same_bits(want[1, 1], np.full(want.shape[2:], 4321, np.float32), 'constant plane, case %d' % k)
