@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""First, second and third forward of a fresh model per precision (batch 500 / 512 of 32 x 32 patches): what a process pays once
+for a kernel's first launch (code load, launch attributes, workspace) — ~1 ms (profiles/r04_k_first_use.txt).
+
+    python tools/first_use_probe.py
+"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from dsen2_amd import weights as W
