@@ -30,6 +30,8 @@ def lib():
         _lib.dsen2_oracle_forward_f64.restype = ctypes.c_int
         _lib.dsen2_oracle_upsample_f64.argtypes = [fp, fp, i, i, i, i, i]
         _lib.dsen2_oracle_upsample_f64.restype = None
+        _lib.dsen2_oracle_upsample_skimage.argtypes = [fp, fp, i, i, i, i, i]
+        _lib.dsen2_oracle_upsample_skimage.restype = None
     return _lib
 
 
@@ -67,11 +69,14 @@ def forward(inputs, flat_weights, num_layers, feature_size):
     return out
 
 
-def upsample(image_lr, oh, ow):
+def upsample(image_lr, oh, ow, skimage=False):
+    """interp_patches on the C side.  skimage=False: exact (double) coordinates and blend — the mathematical definition;
+    skimage=True: scikit-image 0.18.3's float32 arithmetic operation by operation (the reference's bits)."""
     x = np.ascontiguousarray(image_lr, np.float32)
     lead = x.shape[:-2]
     h, w = x.shape[-2:]
     planes = int(np.prod(lead)) if lead else 1
     out = np.empty(lead + (oh, ow), np.float32)
-    lib().dsen2_oracle_upsample_f64(_fp(x), _fp(out), planes, h, w, oh, ow)
+    fn = lib().dsen2_oracle_upsample_skimage if skimage else lib().dsen2_oracle_upsample_f64
+    fn(_fp(x), _fp(out), planes, h, w, oh, ow)
     return out

@@ -102,6 +102,58 @@ static int mirror_index(long i, int dim)
 }
 
 /*
+ * interp_patches (utils/patches.py:11-16) in scikit-image 0.18.3's OWN arithmetic for a float32 image, operation by
+ * operation (the second, independent restatement of oracle/patches_oracle.py's f32_coords mode; both reproduce the captured
+ * outputs of the reference bit for bit, tests/test_oracle_cnn.py):
+ *   warp() casts its matrix to float32:  c = float32(scale) * float32(j) + float32(offset), two rounded operations;
+ *   bilinear_interpolation[float32]:     dc = c - floor(c) in float32;
+ *       top = (1.0 - (double)dc) * (double)top_left + (double)(dc * top_right)     <- that product alone is float32 x float32
+ *       out = (float)((1.0 - (double)dr) * top + (double)dr * bottom)
+ *   then clipped to the plane's [min, max] (warp(clip=True); a no-op for this arithmetic, kept for fidelity) and * 30000.
+ * `volatile` keeps every float32 intermediate a float32 whatever the compiler's evaluation method or contraction rules.
+ */
+void dsen2_oracle_upsample_skimage(const float *in, float *out, int planes, int h, int w, int oh, int ow)
+{
+    const float sy = (float)((double)h / oh), sx = (float)((double)w / ow);
+    const float oy = (float)(0.5 * ((double)h / oh) - 0.5), ox = (float)(0.5 * ((double)w / ow) - 0.5);
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < planes; ++p) {
+        const float *src = in + (size_t)p * h * w;
+        float *dst = out + (size_t)p * oh * ow;
+        float lo = src[0] / 30000.0f, hi = lo;
+        for (size_t k = 1; k < (size_t)h * w; ++k) {
+            const float q = src[k] / 30000.0f;
+            lo = q < lo ? q : lo;
+            hi = q > hi ? q : hi;
+        }
+        for (int i = 0; i < oh; ++i) {
+            volatile float rm = sy * (float)i;
+            volatile float r = rm + oy;
+            const float rf = floorf(r);
+            volatile float drf = r - rf;
+            const double dr = (double)drf;
+            const int ra = mirror_index((long)rf, h), rb = mirror_index((long)ceilf(r), h);
+            for (int j = 0; j < ow; ++j) {
+                volatile float cm = sx * (float)j;
+                volatile float c = cm + ox;
+                const float cf = floorf(c);
+                volatile float dc = c - cf;
+                const int ca = mirror_index((long)cf, w), cb = mirror_index((long)ceilf(c), w);
+                volatile float tl = src[(size_t)ra * w + ca] / 30000.0f, tr = src[(size_t)ra * w + cb] / 30000.0f;
+                volatile float bl = src[(size_t)rb * w + ca] / 30000.0f, br = src[(size_t)rb * w + cb] / 30000.0f;
+                volatile float ptr_ = dc * tr, pbr = dc * br;                    /* float32 products */
+                const double top = (1.0 - (double)dc) * (double)tl + (double)ptr_;
+                const double bot = (1.0 - (double)dc) * (double)bl + (double)pbr;
+                volatile float v = (float)((1.0 - dr) * top + dr * bot);
+                v = v < lo ? lo : (v > hi ? hi : v);
+                volatile float scaled = v * 30000.0f;
+                dst[(size_t)i * ow + j] = scaled;
+            }
+        }
+    }
+}
+
+/*
  * interp_patches (utils/patches.py:11-16): per plane, resize(x/30000, (oh,ow), mode='reflect')*30000.
  * Half-pixel-centre bilinear: src = (dst + 0.5) * (in/out) - 0.5; neighbours floor/ceil, mirrored.
  * Computed in double from the float32 inputs; result rounded to float32 like the reference's store.

@@ -89,3 +89,10 @@ def test_c_upsample_matches_numpy_and_reference(golden_dir):
         n = po.interp_patches(g[src], g[key].shape)
         np.testing.assert_allclose(c, n, rtol=2e-7, atol=1e-3)           # same maths, both exact coords
         np.testing.assert_allclose(c, g[key], rtol=0, atol=3e-2)         # vs skimage (f32 coords)
+        # the C restatement of scikit-image's own float32 arithmetic: the reference's bits, like the numpy one
+        cs = c_oracle.upsample(g[src], oh, ow, skimage=True)
+        assert cs.tobytes() == g[key].tobytes() == po.interp_patches(g[src], g[key].shape, f32_coords=True).tobytes(), key
+    gs = np.load(os.path.join(golden_dir, 'interp_shapes.npz'))
+    for k in range(len([f for f in gs.files if f.startswith('in_')])):
+        x, want = gs['in_%02d' % k], gs['out_%02d' % k]
+        assert c_oracle.upsample(x, want.shape[2], want.shape[3], skimage=True).tobytes() == want.tobytes(), k
