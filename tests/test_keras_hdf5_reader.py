@@ -202,3 +202,48 @@ def test_when_numbering_and_layer_names_order_both_fit_but_differ_keras_order_wi
     a, b = flat[n0:n0 + nb], flat[n0 + nb:n0 + 2 * nb]
     assert np.array_equal(got[:n0], flat[:n0]) and np.array_equal(got[n0:n0 + nb], b) and np.array_equal(got[n0 + nb:n0 + 2 * nb], a)
     assert np.array_equal(got[n0 + 2 * nb:], flat[n0 + 2 * nb:])
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_DATA), reason='the reference checkout is only present in the build container')
+def test_the_reference_demo_readh5_runs_on_the_own_reader(monkeypatch):
+    """testing/demoDSen2.py:14-28 `readh5` — the reference's own function, imported from its unmodified file (its imports of
+    `supres` and matplotlib stubbed: neither is used by readh5) — gives the same arrays with this package's hdf5_min standing in
+    for h5py as with h5py itself, and they are what cli._load returns: a user without h5py can run the demo's reader as it is
+    (`sys.modules['h5py'] = dsen2_amd.hdf5_min`)."""
+    import importlib.util
+    import types
+    from dsen2_amd import cli, hdf5_min
+
+    def load_demo(h5):
+        stubs = {'supres': types.ModuleType('supres'), 'matplotlib': types.ModuleType('matplotlib'),
+                 'matplotlib.pyplot': types.ModuleType('matplotlib.pyplot'), 'h5py': h5}
+        stubs['supres'].DSen2_20 = stubs['supres'].DSen2_60 = None
+        stubs['matplotlib'].pyplot = stubs['matplotlib.pyplot']
+        saved = {k: sys.modules.get(k) for k in list(stubs) + ['utils', 'utils.imresize']}
+        sys.modules.update(stubs)
+        sys.path.insert(0, '/root/reference/testing')
+        sys.path.insert(0, '/root/reference')
+        try:
+            spec = importlib.util.spec_from_file_location('reference_demo_%s' % h5.__name__.replace('.', '_'),
+                                                          '/root/reference/testing/demoDSen2.py')
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)         # `if __name__ == '__main__'` keeps the demo itself from running
+        finally:
+            sys.path.remove('/root/reference/testing')
+            sys.path.remove('/root/reference')
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+        mod.DATA_PATH = REFERENCE_DATA + '/'
+        return mod
+    with_h5py, with_own = load_demo(h5py), load_demo(hdf5_min)
+    for mat in ('S2A_MSIL1C_20170527_T33UUB.mat', 'S2B_MSIL1C_20171022_T49JGM.mat'):
+        a = with_h5py.readh5(mat, im60=True)
+        b = with_own.readh5(mat, im60=True)
+        c = cli._load(os.path.join(REFERENCE_DATA, mat))
+        assert len(a) == len(b) == 3
+        for x, y, z in zip(a, b, c):
+            assert x.dtype == y.dtype == z.dtype and x.shape == y.shape and np.array_equal(x, y) and np.array_equal(x, z)
+        assert len(with_own.readh5(mat)) == 2
