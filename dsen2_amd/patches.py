@@ -33,18 +33,70 @@ def default_device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
+def _storage_plan(a):
+    """How a non-C-contiguous ndarray can be uploaded WITHOUT a strided pass over it on the host.
+
+    The reference's own callers hand over views: `np.rollaxis(ds.ReadAsArray(...), 0, 3)` (testing/s2_tiles_supres.py: an HWC
+    view of a CHW array), `f['im10'][()].transpose()` (testing/demoDSen2.py:16: Fortran order), and under torch.distributed a
+    row slab `d[r0:r1]` of either.  numpy needs seconds to make a 10980^2 x 4 view of that kind C-contiguous — longer than the
+    GPU needs for the whole tile in the bf16 modes — while the storage underneath is contiguous as it is.  Returns
+    (order, mode): `a.transpose(order)` lists the axes by decreasing stride; mode 'whole' = that array is C-contiguous (one
+    copy), 'planes' = each `a.transpose(order)[k]` is (a row slab of a plane-major array: one copy per plane), None = neither
+    (the caller falls back to np.ascontiguousarray)."""
+    if a.ndim < 2 or a.size == 0 or any(st <= 0 for st in a.strides):
+        return None, None
+    order = tuple(int(i) for i in np.argsort([-st for st in a.strides], kind='stable'))
+    base = a.transpose(order)
+    if base.flags.c_contiguous:
+        return order, 'whole'
+    if base.shape[0] <= 64 and base[0].flags.c_contiguous:
+        return order, 'planes'
+    return None, None
+
+
+_TORCH_BITS = {np.uint16: torch.int16, np.int16: torch.int16, np.uint8: torch.uint8, np.int8: torch.int8, np.int32: torch.int32,
+               np.float32: torch.float32}
+
+
+def _widen(t, np_dtype):
+    """The uploaded integer tensor (uint16 travels as int16 bits) -> float32, on the GPU."""
+    if np_dtype == np.uint16:
+        return (t.to(torch.int32) & 0xFFFF).to(torch.float32)
+    return t.to(torch.float32)
+
+
 def _to_device_f32(a, device):
     """Any real array -> contiguous float32 CUDA tensor (the reference's float32 patch arrays take any dtype).
     Integer rasters (Sentinel-2 L1C is uint16) are uploaded as they are and widened on the GPU: half the PCIe
-    bytes and no host-side conversion pass (0.15 s of a 10980^2 tile)."""
+    bytes and no host-side conversion pass (0.15 s of a 10980^2 tile).  Views whose storage is contiguous in another axis
+    order (_storage_plan) are uploaded in THAT order and permuted on the GPU."""
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=torch.float32).contiguous()
+    a = np.asarray(a)
+    direct = a.dtype in (np.uint16, np.int16, np.uint8, np.int8, np.int32, np.float32)
+    if direct and not a.flags.c_contiguous:
+        order, mode = _storage_plan(a)
+        if mode is not None:
+            base = a.transpose(order)
+            if not base.flags.writeable:
+                base = None if mode == 'whole' else base       # (read-only maps: the plane copies below make their own arrays)
+            if base is not None:
+                as_bits = (lambda x: x.view(np.int16)) if a.dtype == np.uint16 else (lambda x: x)
+                if mode == 'whole':
+                    t = torch.from_numpy(as_bits(base)).to(device)
+                else:
+                    t = torch.empty(base.shape, dtype=_TORCH_BITS[a.dtype.type], device=device)
+                    for k in range(base.shape[0]):
+                        plane = base[k] if base[k].flags.writeable else np.array(base[k])
+                        t[k].copy_(torch.from_numpy(as_bits(plane)))
+                inverse = [order.index(i) for i in range(a.ndim)]
+                # permuted at the storage width (2 B for a Sentinel-2 raster), widened after
+                return _widen(t.permute(*inverse).contiguous(), a.dtype)
     a = np.ascontiguousarray(a)
     if not a.flags.writeable:
         a = np.array(a)           # a read-only memory map (cli._load under torch.distributed): copy the slab, not a view torch would warn about
     if a.dtype == np.uint16:
-        t = torch.from_numpy(a.view(np.int16)).to(device)
-        return (t.to(torch.int32) & 0xFFFF).to(torch.float32)
+        return _widen(torch.from_numpy(a.view(np.int16)).to(device), np.uint16)
     if a.dtype in (np.int16, np.uint8, np.int8, np.int32):
         return torch.from_numpy(a).to(device).to(torch.float32)
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)

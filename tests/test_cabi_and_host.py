@@ -194,3 +194,20 @@ def test_overriding_the_product_library_is_never_silent(tmp_path):
     env.pop('DSEN2_HIP_LIB')
     p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and 'overrides' not in p.stderr
+
+
+def test_storage_plan_of_the_views_the_reference_scripts_hand_over():
+    """patches._storage_plan (host logic of the upload): the HWC view of a CHW array (`np.rollaxis(ReadAsArray(...), 0, 3)`,
+    testing/s2_tiles_supres.py) and the transposed array of `readh5` (testing/demoDSen2.py:16) are contiguous in another axis
+    order — uploaded as they lie, permuted on the GPU; a row slab of the former is one contiguous piece per plane; anything
+    else (a column stride, a reversed axis) is not claimed."""
+    from dsen2_amd.patches import _storage_plan
+    chw = np.arange(4 * 6 * 8, dtype=np.uint16).reshape(4, 6, 8)
+    hwc = np.rollaxis(chw, 0, 3)
+    assert not hwc.flags.c_contiguous and _storage_plan(hwc) == ((2, 0, 1), 'whole')
+    assert hwc.transpose(2, 0, 1).flags.c_contiguous
+    assert _storage_plan(chw.transpose()) == ((2, 1, 0), 'whole')
+    order, mode = _storage_plan(hwc[2:5])
+    assert (order, mode) == ((2, 0, 1), 'planes') and all(hwc[2:5].transpose(order)[k].flags.c_contiguous for k in range(4))
+    for other in (hwc[:, ::2], np.ascontiguousarray(hwc)[::-1], chw.transpose()[2:5], np.zeros((0, 3, 4))[:, ::2]):
+        assert _storage_plan(other) == (None, None)

@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -329,3 +330,36 @@ def test_any_real_dtype_and_memory_layout_gives_the_float32_result(model_dir):
     small = (base10 % 256).astype(np.uint8), (base20 % 256).astype(np.uint8)
     want8, _ = quiet(DSen2_20, small[0].astype(np.float32), small[1].astype(np.float32), deep=False)
     assert np.array_equal(quiet(DSen2_20, small[0], small[1], deep=False)[0], want8)
+
+
+@pytest.mark.parametrize('dtype', [np.uint16, np.float32, np.int16])
+def test_views_as_the_reference_scripts_build_them_give_the_same_image(dtype, model_dir):
+    """The reference's callers pass VIEWS: `np.rollaxis(ds.ReadAsArray(...), 0, 3)` (an HWC view of a CHW array,
+    testing/s2_tiles_supres.py) and `f['im10'][()].transpose()` (Fortran order, testing/demoDSen2.py:16).  They are uploaded in
+    their storage order and permuted on the GPU (patches._to_device_f32); the image is the one the C-contiguous copy gives, bit
+    for bit, and the caller's arrays are left as they were."""
+    from dsen2_amd import patches as gp, supres
+    rng = np.random.default_rng(8)
+    hi = 9000 if dtype != np.int16 else 3000
+    c10 = rng.integers(35, hi, size=(4, 288, 252)).astype(dtype)
+    c20 = rng.integers(35, hi, size=(6, 144, 126)).astype(dtype)
+    c60 = rng.integers(35, hi, size=(2, 48, 42)).astype(dtype)
+    roll = [np.rollaxis(a, 0, 3) for a in (c10, c20, c60)]                                  # HWC views of CHW
+    flat = [np.ascontiguousarray(a) for a in roll]                                            # what they mean
+    fort = [np.asfortranarray(a) for a in flat]                                               # readh5-style
+    assert not roll[0].flags.c_contiguous and not fort[0].flags.c_contiguous
+    for views in (roll, fort):
+        for a, b in zip(views, flat):
+            t = gp._to_device_f32(a, gp.default_device())
+            assert t.is_contiguous() and t.dtype == torch.float32 and np.array_equal(t.cpu().numpy(), b.astype(np.float32))
+    # a row slab of a rolled view (what a rank uploads under torch.distributed): one copy per plane
+    t = gp._to_device_f32(roll[0][40:200], gp.default_device())
+    assert np.array_equal(t.cpu().numpy(), flat[0][40:200].astype(np.float32))
+    want20, _ = quiet(supres.DSen2_20, flat[0], flat[1])
+    want60, _ = quiet(supres.DSen2_60, *flat)
+    keep = [a.copy() for a in (c10, c20, c60)]
+    for views in (roll, fort):
+        got20, _ = quiet(supres.DSen2_20, views[0], views[1])
+        got60, _ = quiet(supres.DSen2_60, *views)
+        assert np.array_equal(got20, want20) and np.array_equal(got60, want60)
+    assert all(np.array_equal(a, b) for a, b in zip((c10, c20, c60), keep))

@@ -34,6 +34,8 @@ ap.add_argument('--deep', action='store_true', help='VDSen2 (d=32, F=256) instea
 ap.add_argument('--lazy', type=int, default=-1, metavar='MARGIN', help='hand the images over as cli.LazyRows (rows read on demand, as the GDAL branch of the command line does under torch.distributed) with this margin of 10 m rows; reports the largest share of rows a rank read')
 ap.add_argument('--plain-batches', action='store_true', help='A/B: cut the patches into memory-bound batches (batch_limit) instead of preferred_batch (bf16 modes: multiples of the CU count, which run the one-launch chain)')
 ap.add_argument('--repeat', type=int, default=1, help='run DSen2_20 this many times in the process and report every time (the first call also pays for the workspace, the prediction buffer and the page-locked output buffer; later calls reuse them)')
+ap.add_argument('--layout', default='c', choices=['c', 'rollaxis', 'transpose'], help="how the caller's arrays lie in memory: C-contiguous HWC, np.rollaxis(chw, 0, 3) as testing/s2_tiles_supres.py builds them from GDAL's ReadAsArray, or chw.transpose() as testing/demoDSen2.py's readh5 returns them")
+ap.add_argument('--host-contiguous', action='store_true', help='A/B: make the views C-contiguous on the host inside the timed call (np.ascontiguousarray: what the upload did before it followed the storage order)')
 ap.add_argument('--port', type=int, default=0, help=argparse.SUPPRESS)
 args = ap.parse_args()
 
@@ -51,6 +53,13 @@ rng = np.random.default_rng(0)
 d10 = rng.integers(35, 13110, size=(n, n, 4), dtype=np.uint16)
 d20 = rng.integers(35, 13110, size=(n // 2, n // 2, 6), dtype=np.uint16)
 d60 = rng.integers(35, 13110, size=(n // 6, n // 6, 2), dtype=np.uint16)
+if args.layout != 'c':
+    def _as_view(a):
+        if args.layout == 'rollaxis':
+            return np.rollaxis(np.ascontiguousarray(np.rollaxis(a, 2, 0)), 0, 3)       # HWC view of a CHW array
+        return np.asfortranarray(a)                                                    # = (c, y, x)-ordered storage, transposed
+    d10, d20, d60 = _as_view(d10), _as_view(d20), _as_view(d60)
+    assert not d10.flags.c_contiguous
 a10, a20, a60 = d10, d20, d60         # the arrays themselves: warm-up crops
 lazy = []
 if args.lazy >= 0:
@@ -71,7 +80,7 @@ else:
     np.save(os.path.join(tmp, 's2_032_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 6, 128, seed=11))
     np.save(os.path.join(tmp, 's2_030_lr_1e-05.npy'), weights.random_he_uniform(12, 2, 6, 128, seed=12))
 supres.MDL_PATH = os.path.join(tmp, '')
-out = {'tile': [n, n], 'data': 'synthetic', 'n_gpus': world, 'precision': supres.PRECISION, 'batches': 'batch_limit' if args.plain_batches else 'preferred_batch', 'deep': bool(args.deep), 'patches20': int(np.ceil(n / 112.0) ** 2), 'patches60': int(np.ceil(n / 168.0) ** 2)}
+out = {'tile': [n, n], 'data': 'synthetic', 'n_gpus': world, 'precision': supres.PRECISION, 'batches': 'batch_limit' if args.plain_batches else 'preferred_batch', 'layout': args.layout, 'host_contiguous': bool(args.host_contiguous), 'deep': bool(args.deep), 'patches20': int(np.ceil(n / 112.0) ** 2), 'patches60': int(np.ceil(n / 168.0) ** 2)}
 
 
 def timed(fn, *a):
@@ -85,7 +94,10 @@ def timed(fn, *a):
 
 with contextlib.redirect_stdout(io.StringIO()):
     supres.DSen2_20(a10[:240, :240], a20[:120, :120], args.deep)       # warm-up: library load, model build, weight upload
-y20, t20 = timed(supres.DSen2_20, d10, d20, args.deep)
+run20 = supres.DSen2_20
+if args.host_contiguous:
+    run20 = lambda a, b, deep: supres.DSen2_20(np.ascontiguousarray(a), np.ascontiguousarray(b), deep)      # noqa: E731
+y20, t20 = timed(run20, d10, d20, args.deep)
 if world > 1:                       # whole-job wall time: the slowest rank's
     tt = torch.tensor([t20], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
     td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -95,7 +107,7 @@ if args.repeat > 1:
     runs = [round(t20, 3)]
     for _ in range(args.repeat - 1):
         y20 = None
-        y20, t = timed(supres.DSen2_20, d10, d20, args.deep)
+        y20, t = timed(run20, d10, d20, args.deep)
         runs.append(round(t, 3))
     out['dsen2_20_s_runs'] = runs
 out['dsen2_20_patches_per_s_128'] = round(out['patches20'] / t20, 1)

@@ -24,7 +24,10 @@ from dsen2_amd import supres, weights          # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--tile', default='T33UUB')
+ap.add_argument('--pinned-min-bytes', type=int, default=-1, help='override supres.PINNED_OUTPUT_MIN_BYTES (A/B of the page-locked download threshold)')
 args = ap.parse_args()
+if args.pinned_min_bytes >= 0:
+    supres.PINNED_OUTPUT_MIN_BYTES = args.pinned_min_bytes
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'tile_%s_600.npz' % args.tile))
 d10, d20, d60 = g['d10'], g['d20'], g['d60']
 tmp = tempfile.mkdtemp()
@@ -59,6 +62,6 @@ for prec in ('fp32', 'bf16x3', 'bf16'):
             m.forward_device(xs, out=out)
         torch.cuda.synchronize()
         net = (time.perf_counter() - t0) / 20
-        print(json.dumps({'call': name, 'precision': prec, 'tile': [600, 600], 'patches': n, 'call_ms_median': round(float(np.median(ts)) * 1e3, 2),
+        print(json.dumps({'pinned_min_bytes': supres.PINNED_OUTPUT_MIN_BYTES, 'call': name, 'precision': prec, 'tile': [600, 600], 'patches': n, 'call_ms_median': round(float(np.median(ts)) * 1e3, 2),
                           'call_ms_min': round(min(ts) * 1e3, 2), 'network_alone_ms': round(net * 1e3, 2),
                           'host_side_adds_ms': round((float(np.median(ts)) - net) * 1e3, 2)}), flush=True)
