@@ -207,6 +207,11 @@ def test_storage_plan_of_the_views_the_reference_scripts_hand_over():
     assert not hwc.flags.c_contiguous and _storage_plan(hwc) == ((2, 0, 1), 'whole')
     assert hwc.transpose(2, 0, 1).flags.c_contiguous
     assert _storage_plan(chw.transpose()) == ((2, 1, 0), 'whole')
+    # exactly what testing/s2_tiles_supres.py:313-315 passes: the rolled view indexed by the validated band list — numpy lays
+    # the result of that advanced index out band-major (also when the source is C-contiguous)
+    picked = np.rollaxis(chw, 0, 3)[:, :, [2, 1, 0, 3]]
+    assert not picked.flags.c_contiguous and _storage_plan(picked) == ((2, 0, 1), 'whole')
+    assert _storage_plan(np.ascontiguousarray(hwc)[:, :, [2, 1, 0, 3]]) == ((2, 0, 1), 'whole')
     order, mode = _storage_plan(hwc[2:5])
     assert (order, mode) == ((2, 0, 1), 'planes') and all(hwc[2:5].transpose(order)[k].flags.c_contiguous for k in range(4))
     for other in (hwc[:, ::2], np.ascontiguousarray(hwc)[::-1], chw.transpose()[2:5], np.zeros((0, 3, 4))[:, ::2]):
