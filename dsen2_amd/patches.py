@@ -55,7 +55,7 @@ def _storage_plan(a):
 
 
 _TORCH_BITS = {np.uint16: torch.int16, np.int16: torch.int16, np.uint8: torch.uint8, np.int8: torch.int8, np.int32: torch.int32,
-               np.float32: torch.float32}
+               np.int64: torch.int64, np.float32: torch.float32, np.float64: torch.float64}
 
 
 def _widen(t, np_dtype):
@@ -73,7 +73,7 @@ def _to_device_f32(a, device):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=torch.float32).contiguous()
     a = np.asarray(a)
-    direct = a.dtype in (np.uint16, np.int16, np.uint8, np.int8, np.int32, np.float32)
+    direct = a.dtype.type in _TORCH_BITS and a.dtype.isnative
     if direct and not a.flags.c_contiguous:
         order, mode = _storage_plan(a)
         if mode is not None:
@@ -97,7 +97,9 @@ def _to_device_f32(a, device):
         a = np.array(a)           # a read-only memory map (cli._load under torch.distributed): copy the slab, not a view torch would warn about
     if a.dtype == np.uint16:
         return _widen(torch.from_numpy(a.view(np.int16)).to(device), np.uint16)
-    if a.dtype in (np.int16, np.uint8, np.int8, np.int32):
+    if direct:
+        # converted on the GPU with the same round-to-nearest as numpy's cast into the reference's float32 patch arrays (a
+        # float64 raster: twice the PCIe bytes, but no pass over it on the host)
         return torch.from_numpy(a).to(device).to(torch.float32)
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
 

@@ -330,6 +330,14 @@ def test_any_real_dtype_and_memory_layout_gives_the_float32_result(model_dir):
     small = (base10 % 256).astype(np.uint8), (base20 % 256).astype(np.uint8)
     want8, _ = quiet(DSen2_20, small[0].astype(np.float32), small[1].astype(np.float32), deep=False)
     assert np.array_equal(quiet(DSen2_20, small[0], small[1], deep=False)[0], want8)
+    # float64 values that are NOT float32 numbers (converted on the GPU: the same round-to-nearest as numpy's cast), int64, and a
+    # big-endian array (converted on the host)
+    frac10, frac20 = base10 + rng.random(base10.shape) * 0.999, base20 + rng.random(base20.shape) * 0.999
+    assert frac10.dtype == np.float64 and not np.array_equal(frac10, frac10.astype(np.float32))
+    wantf, _ = quiet(DSen2_20, frac10.astype(np.float32), frac20.astype(np.float32), deep=False)
+    assert np.array_equal(quiet(DSen2_20, frac10, frac20, deep=False)[0], wantf)
+    assert np.array_equal(quiet(DSen2_20, np.asfortranarray(frac10), frac20, deep=False)[0], wantf)
+    assert np.array_equal(quiet(DSen2_20, base10.astype(np.int64), base20.astype('>u2'), deep=False)[0], want)
 
 
 @pytest.mark.parametrize('dtype', [np.uint16, np.float32, np.int16])
