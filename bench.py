@@ -60,7 +60,8 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU work for cpu_baseline')
-    ap.add_argument('--roofline-seconds', type=float, default=5.0, help='GPU time of the instrumented passes behind `roofline`, and again of their event-free replay: ~10 s of uninterrupted GPU work at the default, long enough for an outside utilisation sampler to see the card busy (the timed loop itself is 0.26 s); 1.5 s gives the same numbers (profiles/r04_ablation.md §5)')
+    ap.add_argument('--roofline-seconds', type=float, default=1.5, help='GPU time of the instrumented passes behind `roofline` (right after the timed loop, same clock state), and again of their event-free replay')
+    ap.add_argument('--sustain-seconds', type=float, default=5.0, help='then this many seconds of plain forward passes: `roofline.sustained_ms_per_step`, the rate the chip holds once it is thermally settled (the timed loop itself is 0.26 s) — also what lets an outside utilisation sampler see the card busy; 0 skips it')
     ap.add_argument('--no-gather', action='store_true', help='skip the per-step output all-gather (N>1)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices; '
@@ -196,7 +197,7 @@ def main():
         #     convolutions, output convolution — consecutive intervals between the same time stamps, so
         #     launches x ms_per_launch + first_ms + out_ms = forward_ms by construction
         #     (3 plain passes are enqueued right before them, no synchronisation in between: the GPU is at its steady clock)
-        # at least `steps` instrumented passes, as many as fit --roofline-seconds (5 s: ~390 at the default config): a stable mean
+        # at least `steps` instrumented passes, as many as fit --roofline-seconds (1.5 s: ~100 at the default config): a stable mean
         n_prof = max(args.steps, min(int(100 * args.roofline_seconds / 1.5), int(1e3 * args.roofline_seconds / max(ms_per_step, 1e-3))))
         prof = model.profile_forward(xs, out=outs[0], iters=n_prof, warm=3)
         ms = prof['body_ms'] / (2 * NUM_LAYERS)
@@ -212,6 +213,16 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         replay_ms = e0.elapsed_time(e1) / n_prof
+        # (1c) sustained: several seconds of the same passes, back to back after the above
+        sustained_ms, n_sus = None, 0
+        if args.sustain_seconds > 0:
+            n_sus = max(1, int(1e3 * args.sustain_seconds / max(ms_per_step, 1e-3)))
+            e0.record()
+            for _ in range(n_sus):
+                model.forward_device(xs, out=outs[0])
+            e1.record()
+            torch.cuda.synchronize()
+            sustained_ms = e0.elapsed_time(e1) / n_sus
         # (2) each epilogue alone, back to back, on dense random operands (no ReLU zeros: the chip clocks lower)
         x3 = cfg['precision'] == 'bf16x3'
         ms_relu = ms_res = None
@@ -271,6 +282,10 @@ def main():
                               'forward_period_ms': round(prof['wall_ms'], 4), 'replay_ms_per_step': round(replay_ms, 4),
                               'event_cost_ms': round(prof['wall_ms'] - replay_ms, 4),
                               'replay_vs_timed_loop_ms': round(replay_ms - ms_per_step, 4),
+                              # the step the chip holds over --sustain-seconds of uninterrupted passes (thermally settled; the
+                              # figures above are from the first ~3 s after start-up)
+                              'sustained_ms_per_step': round(sustained_ms, 4) if sustained_ms is not None else None,
+                              'sustained_passes': n_sus,
                               'ms_relu_randn': round(ms_relu, 4) if ms_relu is not None else None,
                               'ms_residual_randn': round(ms_res, 4) if ms_res is not None else None,
                               'flop_per_launch': flops * per_launch,

@@ -23,7 +23,7 @@ def _free_port():
 def test_bench_two_ranks_gloo_rehearsal():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', _free_port(), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
-           '--warmup', '1', '--batch', '64', '--backend', 'gloo', '--roofline-seconds', '0.5']
+           '--warmup', '1', '--batch', '64', '--backend', 'gloo', '--roofline-seconds', '0.5', '--sustain-seconds', '0.3']
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
@@ -34,7 +34,7 @@ def test_bench_two_ranks_gloo_rehearsal():
 
 
 def test_bench_single_gpu_line_has_contract_fields():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-budget', '2', '--roofline-seconds', '0.5'],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-budget', '2', '--roofline-seconds', '0.5', '--sustain-seconds', '0.3'],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
@@ -50,7 +50,7 @@ def test_bench_line_closes_on_itself_and_other_configs_run():
     traffic figure is quoted only with the ISA hash of this build; the bf16x3 config reports dtype "bf16x3" against the bf16
     peak with three MFMAs per product and never claims the headline metric."""
     def line(*extra):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline', '--roofline-seconds', '0.5'] + list(extra),
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline', '--roofline-seconds', '0.5', '--sustain-seconds', '0.3'] + list(extra),
                            capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-2000:]
         return json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
