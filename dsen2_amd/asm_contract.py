@@ -214,6 +214,9 @@ TRAFFIC_KERNELS = {
     'dsen2_20_fp32': ('conv3x3_body32.hip', r'conv3x3_body32_kernelILi128ELi128ELi0ELi0ELi0ELb1ELb1E'),
     'vdsen2_20_bf16': ('conv3x3_body16w.hip', r'conv3x3_body16w_chain_kernelILi128ELi256ELi0E'),
     'dsen2_20_bf16x3': ('conv3x3_body16w.hip', r'conv3x3_body16w_x3_chain_kernelILi64ELi128E'),
+    'vdsen2_20_fp32': ('conv3x3_body32.hip', r'conv3x3_body32_kernelILi256ELi256ELi0ELi0ELi0ELb1ELb1E'),
+    'dsen2_20_bf16': ('conv3x3_body16w.hip', r'conv3x3_body16w_chain_kernelILi64ELi128ELi0E'),
+    'vdsen2_20_bf16x3': ('conv3x3_body16w.hip', r'conv3x3_body16w_x3_chain_kernelILi128ELi256E'),
 }
 ISA_JSON = os.path.join(HERE, 'kernel_isa.json')
 

@@ -19,7 +19,7 @@ python3 tools/summarize_rocprof.py $OUT/trace $OUT/kernel_stats.md "rocprofv3 --
 python3 tools/summarize_pmc.py $OUT/pmc.md $OUT/pmc_* > /dev/null
 # the traffic figure bench.py quotes, together with the hash of the ISA it was just measured on (copy over profiles/body_conv_traffic.json)
 case $CFG in
-  dsen2_20_fp32|vdsen2_20_bf16|dsen2_20_bf16x3)
+  dsen2_20_fp32|vdsen2_20_bf16|dsen2_20_bf16x3|vdsen2_20_fp32|dsen2_20_bf16|vdsen2_20_bf16x3)
     python3 tools/update_traffic_json.py $CFG $OUT/pmc.md "profiles/${TAG}_pmc.md = gpurun_out/$TAG/pmc.md (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of tools/profile_round.sh $TAG $CFG; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM for 16-B/lane reads)" $OUT/body_conv_traffic.json ;;
 esac
 cat $OUT/bench.json

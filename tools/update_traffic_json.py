@@ -34,6 +34,13 @@ ROWS = {
     'dsen2_20_bf16x3': (r'conv3x3_body16w_x3_chain_kernel<64, 128>', 512 * 32 * 32 * 128 * (6 * 22 - 2),
                         'conv3x3_body16w_x3_chain_kernel<64,128>: ONE launch = all 12 body convolutions in bf16x3 (the second staging '
                         'of the hi plane, 2 B per value and convolution, is not counted as algorithmic)'),
+    'vdsen2_20_fp32': (r'conv3x3_body32_kernel<256, 256, 0, ', 256 * 32 * 32 * 256 * 4 * 2 + 9 * 256 * 256 * 4,
+                       'conv3x3_body32_kernel<256,256,relu,...,STG,DEFER> (conv-A): 256 MiB in + 256 MiB out + weights'),
+    'dsen2_20_bf16': (r'conv3x3_body16w_chain_kernel<64, 128, 0>', 6 * (512 * 32 * 32 * 128 * (2 + 2) + 512 * 32 * 32 * 128 * (2 + 2 + 2 + 2 + 2)),
+                      'conv3x3_body16w_chain_kernel<64,128,0>: ONE launch = all 12 body convolutions; per block hi read + t written '
+                      '(conv-A), t + hi + lo read + hi + lo written (conv-B), x 6 blocks'),
+    'vdsen2_20_bf16x3': (r'conv3x3_body16w_x3_chain_kernel<128, 256>', 256 * 32 * 32 * 256 * (32 * 22 - 2),
+                         'conv3x3_body16w_x3_chain_kernel<128,256>: ONE launch = all 64 body convolutions in bf16x3'),
 }
 
 
