@@ -11,7 +11,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 from bits import assert_same_bits
 

@@ -18,7 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from dsen2_amd import cli, supres, weights        # noqa: E402
+from dsen2_amd import cli, weights        # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--size', type=int, default=3000)

@@ -6,7 +6,8 @@ sanitizers are not available on this pool.  Build and run:
         -fPIC -std=c11 -shared -o build/asan/libdsen2_oracle.so oracle/dsen2_oracle.c -lm
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python tools/oracle_sanitizer_run.py
 """
-import ctypes, os, sys
+import os
+import sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
