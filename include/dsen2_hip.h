@@ -84,9 +84,10 @@ int dsen2_model_forward(dsen2_model *m, const float *dev_x10, const float *dev_x
                         void *stream);
 
 /* How many kernel launches the 2*num_layers residual-block convolutions of one forward of n patches of h x w take on
- * the current device: 2*num_layers (one per convolution), or 1 — a precision-1 model runs them as ONE persistent
+ * the current device: 2*num_layers (one per convolution), or 1 — a precision-1 or -2 model runs them as ONE persistent
  * "chain" launch when the batch gives every CU whole patches (each workgroup then owns its patches through all layers;
- * e.g. 256 patches of 32x32 on 256 CUs).  Same results either way, bit for bit.  <0 on error. */
+ * e.g. 256 patches of 32x32 on 256 CUs) and the patches are at most 64 x 64 (beyond that the per-layer launches are
+ * measured faster).  Same results either way, bit for bit.  <0 on error. */
 int dsen2_model_body_launches(const dsen2_model *m, int n, int h, int w);
 
 /* Measurement hook (no reference counterpart): `iters` forward passes exactly as dsen2_model_forward enqueues them,
