@@ -82,9 +82,14 @@ def test_dsen2_20_full_tile_identity_and_windows_vs_oracle(model_dir):
     out = quiet(DSen2_20, d10, d20, deep=False)
     assert out.shape == (N, N, 6) and out.dtype == np.float32
     assert np.isfinite(out[::61, ::67]).all()
-    again = quiet(DSen2_20, d10, d20, deep=False)
+    # the second run takes the rasters the way testing/s2_tiles_supres.py:313-322 passes them — band-major storage behind an HWC
+    # view (np.rollaxis of a CHW read) — which are uploaded in storage order and permuted on the GPU
+    v10 = np.rollaxis(np.ascontiguousarray(np.rollaxis(d10, 2, 0)), 0, 3)
+    v20 = np.rollaxis(np.ascontiguousarray(np.rollaxis(d20, 2, 0)), 0, 3)
+    assert not v10.flags.c_contiguous and np.array_equal(v10[5000:5003], d10[5000:5003])
+    again = quiet(DSen2_20, v10, v20, deep=False)
     assert np.array_equal(out, again)                                         # 9801 patches, bit for bit
-    del again
+    del again, v10, v20
     for which in ('first', 'interior', 'last'):
         ref, y0 = oracle_window(d10, d20, model_dir, which)
         got = out[y0:y0 + INNER, y0:y0 + INNER].astype(np.float64) / 2000
@@ -157,11 +162,11 @@ def _free_port():
 
 def test_full_tile_two_ranks_equal_the_single_rank_image_at_10980():
     """supres._run sharded over 2 ranks (gloo, both on the one GPU) at the full size: 4901 + 4900 patches, each rank
-    uploads the row slab its patches read, only rank 0 holds the weight file (C1 broadcast), the inner crops (2.95 GB)
+    uploads the row slab its patches read (of band-major rasters as the reference's tile script builds them: one copy per band), only rank 0 holds the weight file (C1 broadcast), the inner crops (2.95 GB)
     are gathered to rank 0; its image equals the single-rank image bit for bit, rank 1 returns None."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', _free_port(), os.path.join(ROOT, 'tools', 'bench_full_tile.py'), '--size', str(N),
-           '--skip60', '--backend', 'gloo', '--check']
+           '--skip60', '--backend', 'gloo', '--check', '--layout', 'rollaxis']
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
