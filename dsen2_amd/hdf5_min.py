@@ -744,3 +744,29 @@ def read_with(path, fn, advice=''):
                                   % (path, e, '; ' + advice if advice else '')) from e
         with h5py.File(path, 'r') as f:
             return fn(f)
+
+
+def _print_tree(group, indent=0, out=None):
+    import sys
+    out = out or sys.stdout
+    pad = '  ' * indent
+    for k, v in sorted(group.attrs.items()):
+        a = np.asarray(v) if v is not None else None
+        text = 'unsupported type' if a is None else (repr(a.tolist()) if a.size <= 6 else '%s%r' % (a.dtype, a.shape))
+        out.write('%s@%s = %s\n' % (pad, k, text if len(text) < 100 else text[:97] + '...'))
+    for k in group.keys():
+        obj = group[k]
+        if isinstance(obj, Group):
+            out.write('%s%s/\n' % (pad, k))
+            _print_tree(obj, indent + 1, out)
+        else:
+            out.write('%s%s  %s %r\n' % (pad, k, obj.dtype, tuple(obj.shape)))
+
+
+if __name__ == '__main__':
+    # python -m dsen2_amd.hdf5_min FILE : the tree of a checkpoint / .mat (groups, datasets with dtype and shape, attributes)
+    import sys
+    if len(sys.argv) != 2:
+        sys.exit('usage: python -m dsen2_amd.hdf5_min FILE.hdf5|FILE.mat')
+    with File(sys.argv[1]) as _f:
+        _print_tree(_f)

@@ -170,3 +170,16 @@ def test_damaged_files_fail_with_an_exception_never_a_hang_or_wrong_shape(tmp_pa
             outcomes['exception'] += 1
     print(outcomes)
     assert outcomes['same'] + outcomes['different values'] + outcomes['exception'] == 400
+
+
+def test_tree_listing_of_a_checkpoint():
+    """python -m dsen2_amd.hdf5_min FILE: what a user looks at when a checkpoint does not load (layer names, weight names,
+    shapes)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, '-m', 'dsen2_amd.hdf5_min', os.path.join(DIR, 'keras_full_model.h5')], cwd=root,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert 'model_weights/' in p.stdout and '@layer_names' in p.stdout and 'kernel:0  float32 (3, 3, 10, 8)' in p.stdout
+    assert 'optimizer_weights/' in p.stdout
