@@ -10,14 +10,86 @@ Partitioning: contiguous ranges of the row-major patch index, ceil(N/R) per rank
 short or empty).  With backend "nccl" (= RCCL on ROCm) tensors stay on the GPU; with "gloo" (CPU tests)
 they are staged through host memory.
 """
+import contextlib
+import datetime
+import faulthandler
 import os
 import sys
+import threading
+import time
 
 import numpy as np
 import torch
 import torch.distributed as td
 
 BACKENDS = ('nccl', 'gloo')
+# First contact with RCCL must fail FAST and say where: the process-group timeout (torch's default is 10 minutes — longer
+# than the 600 s a driver gives the whole bench) and the limit of every guarded set-up step.  DSEN2_DIST_TIMEOUT overrides.
+# It stays the group's timeout for every later collective too: a rank that arrives at a gather more than this long after
+# the first one (a very slow reader of its rows, say) needs a larger value.
+DIST_TIMEOUT_DEFAULT_S = 120.0
+
+
+def timeout_s():
+    return float(os.environ.get('DSEN2_DIST_TIMEOUT', DIST_TIMEOUT_DEFAULT_S))
+
+
+EXIT_STEP_FAILED = 70          # a guarded step raised
+EXIT_STEP_HUNG = 71            # a guarded step did not return within its limit
+_first_contact = {}            # what init_from_env saw: ranks_in_collective, seconds per set-up step
+
+
+def _say(msg):
+    rank, _, world = launched_world()
+    sys.stderr.write('dsen2_amd.dist[rank %d/%d pid %d]: %s\n' % (rank, world, os.getpid(), msg))
+    sys.stderr.flush()
+
+
+@contextlib.contextmanager
+def guarded_step(name, limit_s=None):
+    """Run one multi-process set-up step (rendezvous, RCCL communicator set-up, the first collectives) so that it either
+    returns, or this rank says WHICH step failed and leaves with a non-zero code inside `limit_s` — torch.distributed.run then
+    ends the other ranks.  Never a retry: a process that has touched the GPU is not re-used (a fresh start is the only
+    retry this pool tolerates).
+      * the step raises            -> one line naming the step and the error, exit EXIT_STEP_FAILED
+      * the step hangs             -> a timer thread prints the step and exits EXIT_STEP_HUNG at `limit_s`; if that thread
+                                      cannot run (the hung call holds the GIL) faulthandler's GIL-free watchdog dumps every
+                                      thread's stack and exits 10 s later
+    Only used where nothing is worth saving (before any result exists)."""
+    limit_s = timeout_s() if limit_s is None else float(limit_s)
+    t0 = time.perf_counter()
+    # said up front, so that the GIL-free watchdog's bare stack dump can be read against it
+    _say("-> step '%s' (limit %.0f s)" % (name, limit_s))
+
+    def _expired():
+        _say("step '%s' did not finish within %.0f s — giving up (exit %d); a hang here is RCCL / rendezvous set-up, not the "
+             'kernels: check HSA_ENABLE_IPC_MODE_LEGACY=0, MASTER_ADDR=127.0.0.1, one visible GPU per rank'
+             % (name, limit_s, EXIT_STEP_HUNG))
+        os._exit(EXIT_STEP_HUNG)
+    timer = threading.Timer(limit_s, _expired)
+    timer.daemon = True
+    timer.start()
+    faulthandler.dump_traceback_later(limit_s + 10.0, exit=True)
+    try:
+        yield
+    except SystemExit:
+        raise
+    except BaseException as e:           # noqa: BLE001 — reported, then the process ends
+        _say("step '%s' FAILED after %.1f s: %s: %s (exit %d)" % (name, time.perf_counter() - t0, type(e).__name__, e,
+                                                                 EXIT_STEP_FAILED))
+        sys.stderr.flush()
+        os._exit(EXIT_STEP_FAILED)
+    finally:
+        timer.cancel()
+        faulthandler.cancel_dump_traceback_later()
+    _first_contact.setdefault('seconds', {})[name] = round(time.perf_counter() - t0, 3)
+
+
+def first_contact():
+    """What init_from_env() established at N > 1 (a copy): `ranks_in_collective` = an all-reduce of 1 over the new group
+    (proof that the backend's collectives saw every rank), `backend`, and the seconds each guarded set-up step took.
+    Empty for a single process."""
+    return dict(_first_contact)
 
 
 def launched_world():
@@ -56,11 +128,29 @@ def init_from_env(backend='nccl'):
     dev = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(dev)
     if world > 1 and not td.is_initialized():
-        if backend == 'nccl':
-            td.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            td.init_process_group('gloo', rank=rank, world_size=world)
+        connect(backend, rank, world, dev)
     return rank, world, dev
+
+
+def connect(backend, rank, world, dev=None):
+    """Join the process group and make first contact, both under guarded_step (fail fast, say where).  `dev` is this rank's
+    GPU for backend 'nccl' (RCCL binds the communicator to it); gloo needs none — which is how the CPU tests drive this."""
+    timeout = datetime.timedelta(seconds=timeout_s())
+    with guarded_step('init_process_group(%s)' % backend):
+        if backend == 'nccl':
+            td.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, timeout=timeout)
+        else:
+            td.init_process_group('gloo', rank=rank, world_size=world, timeout=timeout)
+    # the first collective is where RCCL builds its rings / exchanges IPC handles: do it HERE, guarded, with a payload
+    # that also proves every rank takes part (sum of ones = world), instead of inside the first real transfer
+    with guarded_step('first all_reduce'):
+        cdev = dev if backend == 'nccl' else torch.device('cpu')
+        ones = torch.ones(1, dtype=torch.int64, device=cdev)
+        td.all_reduce(ones)
+        seen = int(ones.item())              # .item() synchronises: the collective has completed
+        if seen != world:
+            raise RuntimeError('all_reduce of 1 over the group gave %d, WORLD_SIZE is %d' % (seen, world))
+    _first_contact.update(ranks_in_collective=seen, backend=backend, timeout_s=timeout_s())
 
 
 def finalize():

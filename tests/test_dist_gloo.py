@@ -144,3 +144,87 @@ def test_launch_environment_is_read_like_torch_distributed_run_sets_it(monkeypat
         monkeypatch.setenv('WORLD_SIZE', '1')
         with pytest.raises(RuntimeError):
             dist.init_from_env('gloo')
+
+
+# ---- first contact fails fast and says where (VERDICT r4 #1a) ----
+
+def _run_py(code, env=None, timeout=120):
+    import subprocess
+    e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    e.update(env or {})
+    return subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_guarded_step_names_a_failing_step_and_exits_non_zero():
+    p = _run_py("from dsen2_amd import dist\n"
+                "with dist.guarded_step('unit step', 30):\n"
+                "    raise OSError('no such peer')\n"
+                "print('not reached')\n", env={'RANK': '3', 'WORLD_SIZE': '8'})
+    assert p.returncode == 70 and 'not reached' not in p.stdout
+    assert "rank 3/8" in p.stderr and "step 'unit step' FAILED" in p.stderr and 'no such peer' in p.stderr
+
+
+def test_guarded_step_ends_a_hung_step_at_its_limit():
+    import time
+    t0 = time.time()
+    p = _run_py("import time\nfrom dsen2_amd import dist\n"
+                "with dist.guarded_step('sleepy step', 2):\n"
+                "    time.sleep(600)\n")
+    assert p.returncode == 71 and time.time() - t0 < 60
+    assert "step 'sleepy step' did not finish within 2 s" in p.stderr
+
+
+def test_guarded_step_has_a_watchdog_that_needs_no_gil():
+    """A step hung inside a C call that keeps the GIL never lets the timer thread run: faulthandler's own thread ends the
+    process (exit 1) with every thread's stack, 10 s after the limit."""
+    import time
+    t0 = time.time()
+    p = _run_py("import ctypes\nfrom dsen2_amd import dist\n"
+                "libc = ctypes.PyDLL(None)\n"                       # PyDLL: calls keep the GIL
+                "with dist.guarded_step('gil-holding step', 1):\n"
+                "    libc.sleep(600)\n")
+    assert p.returncode == 1 and time.time() - t0 < 90
+    assert 'Timeout' in p.stderr and "-> step 'gil-holding step' (limit 1 s)" in p.stderr
+
+
+def test_a_passing_step_leaves_nothing_armed():
+    p = _run_py("import time\nfrom dsen2_amd import dist\n"
+                "with dist.guarded_step('quick', 1):\n    pass\n"
+                "time.sleep(13)\nprint('alive', dist.first_contact()['seconds']['quick'] < 1)\n")
+    assert p.returncode == 0 and 'alive True' in p.stdout
+
+
+_CONNECT = r'''
+import os, sys
+from dsen2_amd import dist
+rank, _, world = dist.launched_world()
+dist.connect('gloo', rank, world)
+fc = dist.first_contact()
+assert fc['ranks_in_collective'] == world and fc['backend'] == 'gloo'
+assert set(fc['seconds']) == {'init_process_group(gloo)', 'first all_reduce'}
+print('connected', rank, fc['ranks_in_collective'])
+dist.finalize()
+'''
+
+
+def test_connect_counts_the_ranks_in_the_first_collective():
+    import subprocess
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, '-c', _CONNECT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(r),
+                                       WORLD_SIZE='3', DSEN2_DIST_TIMEOUT='60')) for r in range(3)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        assert 'connected %d 3' % r in out
+
+
+def test_connect_gives_up_inside_the_timeout_when_a_rank_never_arrives():
+    """WORLD_SIZE says 2, only rank 0 starts: it must not sit in the rendezvous for torch's default 10 minutes — it names
+    the step and exits non-zero within DSEN2_DIST_TIMEOUT (+ the watchdog's 10 s)."""
+    import time
+    t0 = time.time()
+    p = _run_py(_CONNECT, env={'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port()), 'RANK': '0', 'WORLD_SIZE': '2',
+                               'DSEN2_DIST_TIMEOUT': '5'}, timeout=120)
+    assert p.returncode in (70, 71, 1) and time.time() - t0 < 60
+    assert "init_process_group(gloo)" in p.stderr and 'connected' not in p.stdout
