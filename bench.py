@@ -51,6 +51,57 @@ CONFIGS = {
 # peaks: MI355X_MICROARCH.md — FP32 matrix 157.3 TFLOP/s, BF16 MFMA ~2.5 PFLOP/s dense
 
 
+def other_config(name, seconds, dev):
+    """One of the non-headline configs for about `seconds` of GPU time: the same quantities the headline line carries, by the
+    same means — a loop of plain forward passes between two events on the launch stream (value, ms_per_step), then
+    dsen2_model_forward_profile's four-event passes for the dominant kernel's launch duration (roofline_frac)."""
+    import torch
+    from dsen2_amd import weights as dweights
+    from dsen2_amd.DSen2Net import s2model
+    cfg = CONFIGS[name]
+    bands, d, f, n = cfg['bands'], cfg['d'], cfg['f'], cfg['batch']
+    t_setup = time.perf_counter()
+    model = s2model(tuple((b, None, None) for b in bands), num_layers=d, feature_size=f, device=dev, precision=cfg['precision'])
+    model.set_weights_flat(dweights.random_he_uniform(sum(bands), bands[-1], d, f, seed=1))
+    rng = np.random.Generator(np.random.PCG64(0))
+    xs = [torch.from_numpy(rng.random((n, c, H, W), dtype=np.float32) * np.float32(5.0)).to(dev) for c in bands]
+    out = torch.empty((n, bands[-1], H, W), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    t_pre = time.perf_counter()
+    n_warm = 0
+    while time.perf_counter() - t_pre < 0.060 or n_warm < 3:          # back to the steady clock after the set-up's idle stretch
+        model.forward_device(xs, out=out)
+        torch.cuda.synchronize()
+        n_warm += 1
+    est_ms = (time.perf_counter() - t_pre) * 1e3 / n_warm
+    steps = max(3, int(0.6 * seconds * 1e3 / est_ms))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        model.forward_device(xs, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_per_step = e0.elapsed_time(e1) / steps
+    n_prof = max(3, int(0.4 * seconds * 1e3 / ms_per_step))
+    prof = model.profile_forward(xs, out=out, iters=n_prof, warm=3)
+    launches = model.body_launches(n, H, W)
+    ms_launch = prof['body_ms'] / launches
+    flop_launch = n * H * W * 2 * 9 * f * f * (2 * d // launches) * cfg.get('mfmas_per_product', 1)
+    achieved = flop_launch / (ms_launch * 1e-3) / 1e12
+    flop_net = n * H * W * 2 * 9 * (sum(bands) * f + 2 * d * f * f + f * bands[-1])
+    res = {'metric': cfg['metric'], 'value': round(n / (ms_per_step * 1e-3), 1), 'unit': 'patches/s', 'ms_per_step': round(ms_per_step, 4),
+           'steps': steps, 'dtype': cfg['dtype'], 'batch': n, 'workload': cfg['workload'],
+           'net_tflops': round(flop_net / (ms_per_step * 1e-3) / 1e12, 2),
+           'roofline_frac': round(achieved / cfg['peak'], 4), 'achieved_tflops': round(achieved, 2), 'peak_tflops': cfg['peak'],
+           'launches_per_forward': launches, 'ms_per_launch': round(ms_launch, 4), 'profiled_passes': n_prof,
+           'forward_ms': round(prof['forward_ms'], 4), 'first_ms': round(prof['first_ms'], 4), 'out_ms': round(prof['out_ms'], 4),
+           'finite': bool(torch.isfinite(out).all().item()), 'setup_s': round(t_setup, 2)}
+    del model, xs, out
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -62,6 +113,7 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU work for cpu_baseline')
     ap.add_argument('--roofline-seconds', type=float, default=1.5, help='GPU time of the instrumented passes behind `roofline` (right after the timed loop, same clock state), and again of their event-free replay')
     ap.add_argument('--sustain-seconds', type=float, default=5.0, help='then this many seconds of plain forward passes: `roofline.sustained_ms_per_step`, the rate the chip holds once it is thermally settled (the timed loop itself is 0.26 s) — also what lets an outside utilisation sampler see the card busy; 0 skips it')
+    ap.add_argument('--other-seconds', type=float, default=2.0, help='after the headline (N = 1, default config only): this many seconds of GPU time for each of BASELINE configs[2] (DSen2_60 fp32) and configs[4] (VDSen2_20 bf16) -> `other_configs`; 0 skips them')
     ap.add_argument('--no-gather', action='store_true', help='skip the per-step output all-gather (N>1)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo = rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices; '
@@ -91,12 +143,22 @@ def main():
         sys.exit(2)
     # one process per GPU: this rank's device (LOCAL_RANK), the dmabuf-IPC environment RCCL needs (set before HIP
     # initialises) and the process group — the same entry the drop-in CLI uses (dsen2_amd/dist.py)
+    # (at N > 1 it also makes first contact: group timeout 120 s instead of torch's 10 minutes, an all-reduce of 1 that must
+    # give N — any failure names its step and ends the rank with a non-zero code, dsen2_amd/dist.py::guarded_step)
     rank, world, dev = ddist.init_from_env(args.backend)
-
     # ---- setup (untimed): weights on rank 0 -> RCCL broadcast; synthetic inputs in HBM ----
     n_params = dweights.num_params(sum(BANDS), BANDS[-1], NUM_LAYERS, FEAT)
     flat = dweights.random_he_uniform(sum(BANDS), BANDS[-1], NUM_LAYERS, FEAT, seed=1) if rank == 0 else None
-    flat = ddist.broadcast_weights(flat, n_params, device=dev)
+    if world > 1:
+        with ddist.guarded_step('broadcast of the weights (C1)'):
+            flat = ddist.broadcast_weights(flat, n_params, device=dev)
+        # from here on the whole N > 1 run has a deadline below the 600 s a driver allows: whatever hangs later (a gather
+        # that never completes is first ended by RCCL's own watchdog at the group timeout) leaves every thread's stack on
+        # stderr and a non-zero exit code.  (Armed after the guarded steps: they use the same one-shot watchdog.)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get('DSEN2_BENCH_DEADLINE', '480')), exit=True)
+    else:
+        flat = ddist.broadcast_weights(flat, n_params, device=dev)
     model = s2model(tuple((b, None, None) for b in BANDS), num_layers=NUM_LAYERS, feature_size=FEAT, device=dev,
                     precision=cfg['precision'])
     model.set_weights_flat(flat)
@@ -125,23 +187,42 @@ def main():
         if bf:
             rl_a = rl_a.to(torch.bfloat16)      # conv-A writes bf16 into `o`; conv-B updates `r` in place, read as the (hi, lo) planes
 
-    def step(i):
+    # What the gather costs the compute stream (N > 1 only; nothing of this runs at N = 1).  With RCCL `wait()` does not
+    # block the host: it makes the compute stream wait for the collective — so the stall is measured there, between an
+    # event recorded right before the wait and one right after it (both fire at once unless the gather is still running when
+    # the previous forward has finished).  The host-side seconds inside wait() are kept too: that IS the stall under gloo.
+    gw = {'host_s': 0.0, 'events': [], 'on': False}
+
+    def wait_gather(b):
+        if pending[b] is None:
+            return
+        if gw['on']:
+            if args.backend == 'nccl':
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record()
+            t = time.perf_counter()
+            pending[b].wait()
+            gw['host_s'] += time.perf_counter() - t
+            if args.backend == 'nccl':
+                eb.record()
+                gw['events'].append((ea, eb))
+        else:
+            pending[b].wait()
+        pending[b] = None
+
+    def step(i, gather=do_gather):
         """forward of 512 patches into outs[i%2]; then start gathering it to rank 0 (7 peers x 12.6 MB, one xGMI
         link each) without waiting: the handle is waited on before outs[i%2] is written again, two steps later."""
         b = i & 1
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
+        wait_gather(b)
         model.forward_device(xs, out=outs[b])
-        if do_gather:
+        if gather:
             src = outs[b] if args.backend == 'nccl' else outs[b].cpu()
             pending[b] = td.gather(src, gather_list[b] if rank == 0 else None, dst=0, async_op=True)
 
     def drain():
         for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+            wait_gather(b)
 
     # Untimed, before the W warm-up steps: at least ~40 ms of forwards.  After an idle stretch (process start, weight upload) the
     # chip needs ~25 ms of work to reach its steady clock (profiles/r04_ablation.md §2); W steps of a SHORT step (bf16: 1.8 ms)
@@ -155,22 +236,42 @@ def main():
         step(i)
     drain()
     torch.cuda.synchronize()
-    if world > 1:
-        td.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        td.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+
+    def timed_steps(gather):
+        """EXACTLY K steps between barrier + synchronize on both sides.  Returns (seconds incl. the closing barrier, this
+        rank's own seconds up to its last kernel and gather, before that barrier)."""
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, gather)
+        drain()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, own
+
+    gw['on'] = do_gather
+    elapsed, own_s = timed_steps(do_gather)
+    gw['on'] = False
+    diag = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
+        # ---- after the timed region: what makes an N > 1 line explain itself ----
+        # (a) every rank's own step, and how long its compute stream stood waiting for a gather
+        stall_ms = sum(ea.elapsed_time(eb) for ea, eb in gw['events'])
+        # (b) the control: the same K steps, same bracket, with the gather OFF — compute alone on all N GPUs at once
+        elapsed_ng, own_ng = timed_steps(False)
+        mine = torch.tensor([own_s, stall_ms * 1e-3, gw['host_s'], elapsed_ng, own_ng], dtype=torch.float64, device=cdev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        td.all_gather(every, mine)
+        every = np.array([e.cpu().numpy() for e in every]) / args.steps * 1e3            # [rank, quantity] in ms per step
+        diag = every
     out = outs[(args.steps - 1) & 1]
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -187,6 +288,25 @@ def main():
                    'output_gather': bool(do_gather)},
         'net_tflops': round(value * H * W * FLOP_PER_PIXEL_NET / 1e12, 2),
     }
+    if world > 1:
+        fc = ddist.first_contact()
+        r4 = lambda col: [round(float(v), 4) for v in diag[:, col]]      # noqa: E731
+        result.update({
+            # all-reduce of 1 over the group at start-up: the collectives really spanned N ranks
+            'ranks_in_collective': fc.get('ranks_in_collective'),
+            'dist_setup_s': fc.get('seconds'),
+            # each rank's own K steps (its kernels + its gathers, before the closing barrier) — `ms_per_step` is the slowest
+            # rank's incl. that barrier
+            'per_rank_ms_per_step': {'min': round(float(diag[:, 0].min()), 4), 'max': round(float(diag[:, 0].max()), 4), 'ranks': r4(0)},
+            # time the compute stream stood in `pending[b].wait()` for a gather still in flight (HIP events around the wait;
+            # under gloo the host blocks instead: `host`), per step, per rank — rank 0 receives, the others send
+            'gather_wait_ms_per_step': {'max': round(float(diag[:, 1].max()), 4), 'ranks': r4(1), 'host_max': round(float(diag[:, 2].max()), 4)} if do_gather else None,
+            # the control, same run, same bracket, gather off: what N GPUs computing side by side do without RCCL's kernels
+            # competing with two CU-filling persistent kernels.  ms_per_step - ms_per_step_no_gather = what the gather costs.
+            'ms_per_step_no_gather': round(float(diag[:, 3].max()), 4),
+            'per_rank_ms_per_step_no_gather': {'min': round(float(diag[:, 4].min()), 4), 'max': round(float(diag[:, 4].max()), 4)},
+            'value_no_gather': round(world * args.batch / (float(diag[:, 3].max()) * 1e-3), 1),
+        })
 
     if rank == 0:
         # ---- roofline of the dominant kernel: the 3x3x128x128 body convolution (98.97 % of FLOPs) ----
@@ -294,6 +414,13 @@ def main():
                               'algorithmic_tflops': round(pix * FLOP_PER_PIXEL_BODY / (ms * 1e-3) / 1e12, 2)}
         del a, r, o
         rl_a = rl_r = rl_o = None
+
+    if rank == 0 and world == 1 and args.config == 'dsen2_20_fp32' and args.other_seconds > 0:
+        # ---- the other single-GPU BASELINE configs, on the same box, AFTER everything the headline needs (its timed loop and
+        # roofline legs are over; the chip is warm) — configs[2] DSen2_60 fp32 and configs[4] VDSen2_20 bf16, ~args.other_seconds
+        # of GPU time each.  Not the headline, not `value`: they put two more BASELINE configs on the driver's record.
+        model.release_workspaces()
+        result['other_configs'] = {name: other_config(name, args.other_seconds, dev) for name in ('dsen2_60_fp32', 'vdsen2_20_bf16')}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'dsen2_20_fp32':
         # ---- CPU baseline: the same graph on the host cores, bounded sample (oracle/ = checker code) ----

@@ -205,6 +205,74 @@ def gather_to_root(send, total, dst=0):
     return None
 
 
+def chunk_bounds(per, chunks):
+    """[(c0, c1)] — `per` slots of a rank's send buffer cut into at most `chunks` contiguous pieces of equal size (the last
+    may be short); the same on every rank, so that piece c of every rank is one gather."""
+    if per <= 0:
+        return []
+    size = (per + max(1, int(chunks)) - 1) // max(1, int(chunks))
+    return [(c0, min(per, c0 + size)) for c0 in range(0, per, size)]
+
+
+class ChunkedGather(object):
+    """C2 in pieces (DSEN2_CHUNKED_GATHER): the same [per_rank(total, world), ...] send buffer and the same [world * per, ...]
+    receive buffer on rank `dst` as gather_to_root, but slots [c0, c1) of every rank travel as gather number c — issued
+    asynchronously as soon as a rank has written them, while it goes on computing — so rank `dst` can recompose and download
+    what has arrived under the shards' remaining work instead of after one gather at the very end.
+
+    Every rank must call issue(0 .. n_chunks-1) in order (they are collectives), whatever its share of the work.  RCCL:
+    issue() only enqueues (the collective waits for the compute stream's work up to this point on its own stream);
+    complete(c) makes the CURRENT stream wait for gather c.  gloo (rehearsal): issue() stages the slots through host memory
+    (synchronising with the compute stream), complete(c) blocks the host and uploads what arrived."""
+
+    def __init__(self, send, total, chunks, dst=0):
+        self.rank, self.world = rank_world()
+        self.per = per_rank(total, self.world)
+        assert self.world > 1 and send.shape[0] == self.per, (self.world, send.shape, self.per)
+        self.send, self.total, self.dst = send, total, dst
+        self.bounds = chunk_bounds(self.per, chunks)
+        self.n_chunks = len(self.bounds)
+        self.work = [None] * self.n_chunks
+        self.on_device = td.get_backend() == 'nccl'
+        self.recv = self._staged = None
+        if self.rank == dst:
+            self.recv = torch.empty((self.world * self.per,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+            self._staged = [None] * self.n_chunks
+
+    def _views(self, buf, c0, c1):
+        return [buf[r * self.per + c0:r * self.per + c1] for r in range(self.world)]
+
+    def issue(self, c):
+        assert self.work[c] is None and (c == 0 or self.work[c - 1] is not None), 'gathers are issued once, in order'
+        c0, c1 = self.bounds[c]
+        src = self.send[c0:c1]
+        into = None
+        if self.on_device:
+            if self.rank == self.dst:
+                into = self._views(self.recv, c0, c1)
+        else:
+            src = src.cpu()
+            if self.rank == self.dst:
+                self._staged[c] = torch.empty((self.world, c1 - c0) + tuple(src.shape[1:]), dtype=src.dtype)
+                into = list(self._staged[c].unbind(0))
+        self.work[c] = td.gather(src, into, dst=self.dst, async_op=True)
+
+    def complete(self, c):
+        """Root: everything slots [c0, c1) of every rank hold is in `recv` as far as the current stream is concerned.
+        Other ranks: gather c no longer needs the send buffer."""
+        self.work[c].wait()
+        if self.rank == self.dst and not self.on_device:
+            c0, c1 = self.bounds[c]
+            for r, v in enumerate(self._views(self.recv, c0, c1)):
+                v.copy_(self._staged[c][r])
+            self._staged[c] = None
+        return self.bounds[c]
+
+    def slots_done(self, c):
+        """Number of leading slots of every rank's shard that have arrived once gathers 0..c are complete."""
+        return self.bounds[c][1]
+
+
 def load_weights_on_root(path, cin, cout, num_layers, feature_size, device=None, src=0):
     """C1 as the product path uses it (supres._get_model under an initialised process group): rank `src` alone opens and
     parses the checkpoint (the stand-in for `model.load_weights(predict_file)`, testing/supres.py:63), every rank gets the

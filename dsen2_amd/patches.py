@@ -232,6 +232,27 @@ def recompose_grid(size, patch, border):
     return int(ceil(size[1] / float(inner))), int(ceil(size[0] / float(inner)))    # x_tiles, y_tiles
 
 
+def final_row_runs(have, done_rows, size, inner):
+    """Which image rows can be recomposed now.  `have`: bool per patch (row-major patch index, x_tiles * y_tiles of them) —
+    the patches that are final; `done_rows`: bool per TILE ROW, rows already recomposed (updated in place).  A tile row is
+    ready when all its patches are; tile row ty decides image rows [ty * inner, min((ty + 1) * inner, H - inner)), the last
+    one [H - inner, H) (its start is clamped, patches.py:396-401, and it overwrites what the row before it put there).
+    Returns merged [(row0, row1)] runs in ascending order."""
+    H = int(size[0])
+    x_tiles = int(ceil(size[1] / float(inner)))
+    y_tiles = int(ceil(H / float(inner)))
+    ready = np.asarray(have[:x_tiles * y_tiles], bool).reshape(y_tiles, x_tiles).all(axis=1) & ~done_rows
+    runs = []
+    for ty in np.nonzero(ready)[0]:
+        r0, r1 = (H - inner, H) if ty == y_tiles - 1 else (int(ty) * inner, min((int(ty) + 1) * inner, H - inner))
+        if runs and runs[-1][1] == r0:
+            runs[-1] = (runs[-1][0], r1)
+        else:
+            runs.append((r0, r1))
+        done_rows[ty] = True
+    return runs
+
+
 def recompose_device(a_dev, border, size, scale=1.0):
     """[N,C,P,P] CUDA tensor -> [size0,size1,C] CUDA tensor (N > 1)."""
     n, c, p, _ = a_dev.shape

@@ -129,6 +129,13 @@ def _run(dsets, scales, patch, border, deep, run_60):
     else:
         send = torch.empty((per, cout, inner, inner), dtype=torch.float32, device=dev)
         pred_local = None
+    # Several ranks, DSEN2_CHUNKED_GATHER=1: the crops travel in DSEN2_GATHER_CHUNKS (8) pieces while the shards are still computing
+    # (dist.ChunkedGather) and rank 0 recomposes + downloads what has arrived under the remaining work, instead of one
+    # gather at the very end followed by recomposition and 51 ms of D2H on rank 0 alone.  Off by default until
+    # an N > 1 box has measured RCCL's kernels next to two CU-filling persistent ones; the result is the same image.
+    cg, next_chunk = None, 0
+    if send is not None and _chunked_gather_wanted():
+        cg = _dist.ChunkedGather(send, used, _gather_chunks())
     bands = None                     # one rank, large image: the bands of rows already recomposed (below)
     if count > 0:
         # upload only the rows this rank's patches read (1/world of the tile), origins shifted into the slab
@@ -168,6 +175,10 @@ def _run(dsets, scales, patch, border, deep, run_60):
             else:
                 y = model.forward_device(xs)
                 send[i0:i0 + n].copy_(y[:, :, border:patch - border, border:patch - border])
+                # a piece whose slots this rank has all written (a short shard: all it will ever write) goes out now
+                while cg is not None and next_chunk < cg.n_chunks and i0 + n >= min(cg.bounds[next_chunk][1], count):
+                    cg.issue(next_chunk)
+                    next_chunk += 1
             if bands is not None:
                 done = i0 + n
                 final = int(size[0]) if done == count else min((done // bands['x_tiles']) * inner, int(size[0]) - inner)
@@ -200,6 +211,8 @@ def _run(dsets, scales, patch, border, deep, run_60):
     # Everything above is only ENQUEUED (seconds of GPU work for a full tile): rank 0 allocates the page-locked
     # buffer the result is downloaded into now, under that work (0.18 s for a 10980^2 x 6 image; the download itself
     # then runs at 57 GB/s instead of 11 GB/s from pageable memory: 0.05 s instead of 0.26 s).
+    if cg is not None:
+        return _finish_chunked(cg, next_chunk, rank, dev, size, cout, inner)
     host = _host_output((int(size[0]), int(size[1]), cout)) if rank == 0 else None
     if world == 1:
         print((cout, size[0], size[1]))                                # patches.py:392
@@ -219,6 +232,49 @@ def _run(dsets, scales, patch, border, deep, run_60):
     host.copy_(images, non_blocking=True)
     torch.cuda.synchronize(dev)
     return host.numpy()            # ndarray view of the page-locked tensor (kept alive by the array)
+
+
+def _chunked_gather_wanted():
+    return os.environ.get('DSEN2_CHUNKED_GATHER', '0') not in ('', '0')
+
+
+def _gather_chunks():
+    return max(1, int(os.environ.get('DSEN2_GATHER_CHUNKS', '8')))
+
+
+def _finish_chunked(cg, next_chunk, rank, dev, size, cout, inner):
+    """The tail of a sharded run with the chunked gather.  Every rank: the pieces it has not issued yet (a rank whose shard
+    is short or empty still takes part in every gather).  Rank 0: on a stream of its own — so that its compute stream never
+    waits for RCCL — piece by piece: wait for the gather, recompose the image rows whose patches have all arrived (the crops
+    tile like whole patches with border 0, patches.py:380-403), download them into the page-locked buffer.  All of it is
+    enqueued at once; only the final synchronise blocks."""
+    while next_chunk < cg.n_chunks:
+        cg.issue(next_chunk)
+        next_chunk += 1
+    if rank != 0:
+        for c in range(cg.n_chunks):
+            cg.complete(c)             # the send buffer stays alive until every piece has left
+        return None
+    print((cout, size[0], size[1]))                                    # patches.py:392
+    H, W = int(size[0]), int(size[1])
+    host = _host_output((H, W, cout))
+    img = torch.empty((H, W, cout), dtype=torch.float32, device=dev)
+    x_tiles, y_tiles = int(np.ceil(W / float(inner))), int(np.ceil(H / float(inner)))
+    slot = np.arange(x_tiles * y_tiles) % cg.per                       # a patch's slot in its rank's shard
+    done_rows = np.zeros(y_tiles, bool)
+    tail = torch.cuda.Stream(dev)
+    tail.wait_stream(torch.cuda.current_stream(dev))                   # `img` / `recv` were allocated on the compute stream
+    with torch.cuda.stream(tail):
+        for c in range(cg.n_chunks):
+            cg.complete(c)
+            for r0, r1 in _patches.final_row_runs(slot < cg.slots_done(c), done_rows, size, inner):
+                # `images *= SCALE` (supres.py:29) folded into the recomposition
+                _patches.recompose_rows_device(cg.recv, 0, img, r0, r1, scale=SCALE)
+                if host is not None:
+                    host[r0:r1].copy_(img[r0:r1], non_blocking=True)
+    tail.synchronize()
+    assert done_rows.all()
+    return host.numpy() if host is not None else img.cpu().numpy()
 
 
 PINNED_OUTPUT_MIN_BYTES = 64 << 20     # DSEN2_PINNED_OUTPUT=0 disables; torch caches page-locked blocks for reuse

@@ -228,3 +228,84 @@ def test_connect_gives_up_inside_the_timeout_when_a_rank_never_arrives():
                                'DSEN2_DIST_TIMEOUT': '5'}, timeout=120)
     assert p.returncode in (70, 71, 1) and time.time() - t0 < 60
     assert "init_process_group(gloo)" in p.stderr and 'connected' not in p.stdout
+
+
+# ---- C2 in pieces (DSEN2_CHUNKED_GATHER) ----
+
+def test_chunk_bounds_cover_the_shard_once():
+    from dsen2_amd import dist
+    for per in (0, 1, 2, 7, 8, 9, 154, 1226):
+        for chunks in (1, 2, 3, 8, 50):
+            b = dist.chunk_bounds(per, chunks)
+            assert len(b) <= chunks and [x for c0, c1 in b for x in range(c0, c1)] == list(range(per))
+            assert all(c1 - c0 == b[0][1] - b[0][0] for c0, c1 in b[:-1])
+
+
+def test_final_row_runs_release_every_row_exactly_once_and_only_when_its_patches_are_there():
+    """Against the definition: image row y is decided by tile row (y >= H - inner ? last : y // inner), patches.py:394-403."""
+    from dsen2_amd import patches
+    rng = np.random.default_rng(5)
+    for H, W, inner in ((600, 600, 112), (570, 333, 112), (10980, 10980, 112), (1008, 504, 168), (112, 300, 112), (113, 112 * 3, 112)):
+        x_tiles, y_tiles = -(-W // inner), -(-H // inner)
+        n = x_tiles * y_tiles
+        order = rng.permutation(n)
+        have, done = np.zeros(n, bool), np.zeros(y_tiles, bool)
+        owner = np.where(np.arange(H) >= H - inner, y_tiles - 1, np.arange(H) // inner)
+        seen = np.zeros(H, int)
+        for cut in np.array_split(order, 7):
+            have[cut] = True
+            for r0, r1 in patches.final_row_runs(have, done, (H, W), inner):
+                assert 0 <= r0 < r1 <= H
+                assert have.reshape(y_tiles, x_tiles)[owner[r0:r1]].all()
+                seen[r0:r1] += 1
+        assert (seen == 1).all() and done.all()
+
+
+def _chunked_worker(rank, world, port, total, chunks, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from dsen2_amd import dist
+        first, count = dist.shard_range(total)
+        per = dist.per_rank(total, world)
+        g = torch.Generator().manual_seed(100 + rank)
+        send = torch.rand((per, 2, 3, 3), generator=g)
+        whole = dist.gather_to_root(send.clone(), total)               # the one-shot form: what the pieces must add up to
+        cg = dist.ChunkedGather(send, total, chunks)
+        ok = cg.n_chunks == len(dist.chunk_bounds(per, chunks))
+        # a rank issues a piece once it has "written" it; ranks run at different speeds — the order is what matters
+        for c in range(cg.n_chunks):
+            cg.issue(c)
+        arrived = 0
+        for c in range(cg.n_chunks):
+            c0, c1 = cg.complete(c)
+            if rank == 0:
+                arrived = cg.slots_done(c)
+                for r in range(world):      # everything up to this piece is in place for every rank, bit for bit
+                    lo, hi = r * per, min(total, r * per + arrived)
+                    ok = ok and (hi <= lo or torch.equal(cg.recv[lo:hi], whole[lo:hi]))
+        if rank == 0:
+            ok = ok and arrived == per and torch.equal(cg.recv[:total], whole)
+        else:
+            ok = ok and cg.recv is None and whole is None
+        q.put((rank, bool(ok)))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,total,chunks', [(2, 9, 3), (2, 1, 8), (3, 7, 2), (3, 2, 8), (4, 36, 8), (8, 13, 4), (2, 16, 1)])
+def test_chunked_gather_delivers_what_the_single_gather_delivers(world, total, chunks):
+    """Uneven shards, a rank with nothing ((2, 1), (3, 2), (8, 13)), more pieces asked for than slots, one piece."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunked_worker, args=(r, world, port, total, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res == {r: True for r in range(world)}

@@ -171,3 +171,17 @@ def test_full_tile_two_ranks_equal_the_single_rank_image_at_10980():
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
     assert r['tile'] == [N, N] and r['n_gpus'] == 2 and r['patches20'] == 9801 and r['matches_single_rank'] is True
+
+
+def test_full_tile_chunked_gather_equals_the_single_rank_image_at_10980():
+    """The same run with DSEN2_CHUNKED_GATHER=1: 8 gathers of ~613 crops per rank issued under the shards' work, rank 0
+    recomposes and downloads band by band on its own stream into the page-locked buffer (the full-size image takes that
+    path; the small rehearsal tiles do not)."""
+    env = dict(os.environ, DSEN2_CHUNKED_GATHER='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', _free_port(), os.path.join(ROOT, 'tools', 'bench_full_tile.py'), '--size', str(N),
+           '--skip60', '--backend', 'gloo', '--check']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert r['n_gpus'] == 2 and r['chunked_gather'] is True and r['matches_single_rank'] is True

@@ -135,6 +135,8 @@ if lazy:
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         share = float(tt.item())
     out['largest_share_of_rows_read_by_a_rank'] = round(share, 3)
+if world > 1:
+    out['chunked_gather'] = supres._chunked_gather_wanted()
 if world > 1 and args.check:
     td.barrier()
     td.destroy_process_group()            # dist.rank_world() now reports (0, 1): every rank computes everything
