@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DSEN2_HIP_LIB') or os.path.join(_HERE, 'libdsen2_hip.so')   # override: A/B of experimental builds
 
 OK = 0
-ERR_INVALID, ERR_HIP, ERR_NO_WEIGHTS, ERR_WORKSPACE, ERR_NO_DEVICE = -1, -2, -3, -4, -5
+ERR_INVALID, ERR_HIP, ERR_NO_WEIGHTS, ERR_WORKSPACE, ERR_NO_DEVICE, ERR_NOMEM, ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -114,6 +114,8 @@ def diag_set(key, value):
 
 
 def check(code):
+    if code == ERR_NOMEM:          # the host ran out of memory inside the library: Python's own exception for that
+        raise MemoryError('libdsen2_hip: ' + load().dsen2_last_error().decode('utf-8', 'replace'))
     if code != OK:
         raise DSen2Error(code, load().dsen2_last_error().decode('utf-8', 'replace'))
 

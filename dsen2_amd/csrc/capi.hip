@@ -35,11 +35,11 @@ int guarded(F&& body) noexcept {
   try {
     return body();
   } catch (const std::bad_alloc&) {
-    return fail(DSEN2_ERR_INVALID, "out of host memory");
+    return fail(DSEN2_ERR_NOMEM, "out of host memory");            // not the caller's arguments: its own code
   } catch (const std::exception& e) {
-    return fail(DSEN2_ERR_INVALID, "unexpected C++ exception: %s", e.what());
+    return fail(DSEN2_ERR_INTERNAL, "unexpected C++ exception: %s", e.what());
   } catch (...) {
-    return fail(DSEN2_ERR_INVALID, "unexpected C++ exception");
+    return fail(DSEN2_ERR_INTERNAL, "unexpected C++ exception");
   }
 }
 

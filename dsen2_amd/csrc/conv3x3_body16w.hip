@@ -144,7 +144,22 @@ constexpr int younger_than_input(bool has_w) { return has_w ? 4 * W_PER_STEP : 0
 //     bf16(x - hi) — the stream stays exact fp32, xl exists only as conv-A's second operand plane;
 //   * E_OPS: 32 stores (conv-A), 32 loads + 48 stores (conv-B; the first-chunk waits saturate at vmcnt(63): stricter).
 // Accuracy (tests/test_gpu_bf16x3.py, against float64): whole DSen2_20 network rmse ~1e-5 in the normalised domain against
-// 3e-7 (fp32) and 4e-3 (bf16 operands): inside the 1e-4 gate of BASELINE.md.  Not for CHAIN (per-layer launches).
+// 3e-7 (fp32) and 4e-3 (bf16 operands): inside the 1e-4 gate of BASELINE.md.
+// X3 + CHAIN (conv3x3_body16w_x3_chain_kernel; capi.hip's forward_impl takes it for precision 2 wherever
+// body16w_chain_patches_per_wg gives every CU whole patches): the boundary rules above were derived for one plane and 16 / 32
+// epilogue operations; they carry over because every one of them is stated in CHUNKS of the item loop, and for X3 those are
+// the virtual ones:
+//   * retirement: an item's outputs are retired by the end of the next item's virtual chunk 2 and published by that step's
+//     barrier, exactly as above (the stage-ahead distance is still one chunk of the loop = a third of a real chunk);
+//   * what a distance-1 successor may read: at F = 256 the only distance-1 pair of a one-patch workgroup is (last tile, slab 1)
+//     -> (tile 0, slab 0) of the next layer; slab 1 = real channels 128..255 = real chunks cc >= 4 = VIRTUAL chunks >= 12, in
+//     both planes of a two-plane tensor (a plane is selected by j of v = 3*cc + j, never by cc) — later than the chunk-4
+//     bound the rule needs.  F = 128 with one patch in the workgroup drains, as for precision 1 (ly_seamless is per workgroup);
+//   * the counted waits: E_OPS is 32 (conv-A) / 80 (conv-B); a first-chunk wait that would count more than 63 operations
+//     saturates at vmcnt(63) — it waits for MORE than it has to, never less — and E_FIRST takes the smaller of the two
+//     alternating epilogues at a layer's first item, as for precision 1.
+// tests/test_gpu_bf16x3.py::test_bf16x3_chain_kernel_equals_the_per_layer_kernels_bit_for_bit covers F = 128 and F = 256 with
+// batches that patches_per_wg does not divide (tail workgroup with one patch, one or two tiles per layer).
 
 template <int ABL, bool X3 = false>
 __host__ __device__ constexpr int epilogue_ops(int epi) {

@@ -30,10 +30,50 @@ class UnsupportedHDF5(NotImplementedError):
     """A valid HDF5 feature this reader does not implement (the message names it)."""
 
 
+class _Map(object):
+    """The mapped file, read-only, with ONE rule: a read that reaches past the end of the file (or starts at an undefined
+    address) is a damaged file and says so — a plain mmap slice would silently come back short and decode to a wrong
+    integer or address."""
+    def __init__(self, mm):
+        self._mm, self._n = mm, len(mm)
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            a, b = (0 if k.start is None else k.start), (self._n if k.stop is None else k.stop)
+            if not (isinstance(a, int) and isinstance(b, int)) or a < 0 or b < a or b > self._n or k.step is not None:
+                raise ValueError('HDF5 file truncated or corrupt: bytes [%r, %r) of a %d-byte file' % (k.start, k.stop, self._n))
+            return self._mm[a:b]
+        if not isinstance(k, int) or not 0 <= k < self._n:
+            raise ValueError('HDF5 file truncated or corrupt: byte %r of a %d-byte file' % (k, self._n))
+        return self._mm[k]
+
+    def find(self, what, start, end):
+        if not (isinstance(start, int) and isinstance(end, int)) or start < 0 or end < start or end > self._n:
+            raise ValueError('HDF5 file truncated or corrupt: bytes [%r, %r) of a %d-byte file' % (start, end, self._n))
+        return self._mm.find(what, start, end)
+
+
+def _fletcher32(data):
+    """The checksum the library's fletcher32 filter stores after a chunk (H5_checksum_fletcher32): Fletcher's sums over
+    big-endian 16-bit words, an odd last byte as the high half of a word, each sum folded to 16 bits."""
+    n = len(data) // 2
+    w = np.frombuffer(data, '>u2', n).astype(np.uint64)
+    s1 = int(w.sum())
+    s2 = int((w * np.arange(n, 0, -1, dtype=np.uint64)).sum()) if n < (1 << 24) else sum(int(x) * (n - i) for i, x in enumerate(w))
+    if len(data) & 1:
+        s1 += data[-1] << 8
+        s2 += s1
+    fold = lambda s: (s % 65535) or (65535 if s else 0)      # noqa: E731  (end-around carry: a non-zero multiple of 65535 stays 0xffff)
+    return (fold(s2) << 16) | fold(s1)
+
+
 class _Buf(object):
     """The mapped file with the superblock's sizes: addresses in the file are relative to `base`."""
     def __init__(self, mm):
-        self.mm = mm
+        self.mm = mm if isinstance(mm, _Map) else _Map(mm)
         self.base = 0
         self.O = 8                                  # size of offsets
         self.L = 8                                  # size of lengths
@@ -427,7 +467,12 @@ class Dataset(_Object):
                 continue
             fid = filters[i][0]
             if fid == 3:
-                chunk = chunk[:-4]
+                if len(chunk) < 4:
+                    raise ValueError('HDF5: %s: a fletcher32 chunk of %d bytes' % (self.name, len(chunk)))
+                stored, chunk = int.from_bytes(chunk[-4:], 'little'), chunk[:-4]
+                if _fletcher32(bytes(chunk)) != stored:
+                    raise ValueError('HDF5: %s: fletcher32 checksum mismatch (stored %#010x): the file is damaged'
+                                     % (self.name, stored))
             elif fid == 1:
                 chunk = zlib.decompress(chunk)
             elif fid == 2:

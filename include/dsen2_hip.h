@@ -35,6 +35,11 @@ extern "C" {
 #define DSEN2_ERR_NO_WEIGHTS (-3)  /* forward before load_weights */
 #define DSEN2_ERR_WORKSPACE (-4)   /* workspace too small */
 #define DSEN2_ERR_NO_DEVICE (-5)   /* no gfx950 device visible */
+#define DSEN2_ERR_NOMEM (-6)       /* the HOST ran out of memory inside the library (std::bad_alloc) — not a caller error */
+#define DSEN2_ERR_INTERNAL (-7)    /* any other C++ exception caught at the boundary (a library bug, never a caller error) */
+/* Shape limit of every entry point that takes (n, h, w): ONE image's activation tensor must stay below 2^31 bytes
+ * (h * w * feature_size < 2^29 values) — the kernels address an image through a 32-bit buffer descriptor.  Checked up
+ * front (DSEN2_ERR_INVALID before anything is enqueued), the same for all three precisions; there is no limit on n. */
 
 typedef struct dsen2_model dsen2_model;
 

@@ -223,6 +223,8 @@ def test_precision2_forward_is_the_chain_of_its_kernel_level_operations(d, feat,
     (128, 2, 301, 16, 32),      # ... with a single item per layer in the tail workgroup
     (256, 1, 256, 32, 32),      # F = 256, one patch per workgroup: seamless (slab 1 = virtual input chunks 12-23)
     (256, 1, 256, 48, 40),      # 3 x 2 tiles per patch, ragged last column
+    (256, 2, 511, 32, 32),      # F = 256, two patches per workgroup except the TAIL one (one patch): seamless everywhere
+    (256, 2, 511, 16, 32),      # ... with ONE tile (two items: slab 0, slab 1) per layer in the tail workgroup
 ])
 def test_bf16x3_chain_kernel_equals_the_per_layer_kernels_bit_for_bit(feat, d, n, h, w):
     """precision 2: a batch that gives every CU whole patches runs its 2d body convolutions as ONE chain launch

@@ -183,3 +183,67 @@ def test_tree_listing_of_a_checkpoint():
     assert p.returncode == 0, p.stderr[-1000:]
     assert 'model_weights/' in p.stdout and '@layer_names' in p.stdout and 'kernel:0  float32 (3, 3, 10, 8)' in p.stdout
     assert 'optimizer_weights/' in p.stdout
+
+
+def test_fletcher32_is_verified_and_short_reads_are_errors(tmp_path):
+    """the checksum the library stores after a fletcher32 chunk is CHECKED (the real library's file passes; a
+    stored checksum with one bit flipped is a ValueError naming the dataset), and no read past the end of the map comes
+    back short."""
+    from dsen2_amd import hdf5_min as H
+    blob = bytearray(open(os.path.join(DIR, 'features.h5'), 'rb').read())
+    with H.File(os.path.join(DIR, 'features.h5')) as f:
+        want = f['shuffled'][()]
+        addrs = []
+        f['shuffled']._chunks_for_test(addrs) if hasattr(f['shuffled'], '_chunks_for_test') else None
+    assert want.shape == (50, 70)
+    # odd length + end-around carry, against the definition written out byte by byte
+    def slow(d):
+        s1 = s2 = 0
+        for i in range(0, len(d) - 1, 2):
+            s1 += (d[i] << 8) | d[i + 1]
+            s2 += s1
+        if len(d) & 1:
+            s1 += d[-1] << 8
+            s2 += s1
+        f16 = lambda s: (s % 65535) or (65535 if s else 0)      # noqa: E731
+        return (f16(s2) << 16) | f16(s1)
+    rng = np.random.default_rng(2)
+    for n in (0, 1, 2, 3, 126, 127, 4096, 4097):
+        d = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert H._fletcher32(d) == slow(d), n
+    assert H._fletcher32(b'\xff\xff' * 5) == slow(b'\xff\xff' * 5)
+    # a flipped bit anywhere INSIDE a stored chunk of 'shuffled' (gzip + shuffle + fletcher32) is an exception — caught by zlib
+    # or by the checksum — never different values.  (Bits of the unchecksummed metadata around it can still change what is
+    # read: version-1 B-tree nodes carry no checksum; that is the format, and test_damaged_files_... covers it.)
+    chunks = []
+    real = H.Dataset._unfilter
+
+    def spy(self, chunk, mask, filters, itemsize):
+        raw = bytes(chunk)
+        chunks.append((bytes(blob).find(raw), len(raw)))
+        return real(self, chunk, mask, filters, itemsize)
+    H.Dataset._unfilter = spy
+    try:
+        with H.File(os.path.join(DIR, 'features.h5')) as f:
+            f['shuffled'][()]
+    finally:
+        H.Dataset._unfilter = real
+    assert len(chunks) == 8 * 8 and all(pos > 0 and n > 8 for pos, n in chunks)       # 50 x 70 in chunks of 7 x 9
+    p = str(tmp_path / 'x.h5')
+    for pos, n in chunks[::3]:
+        for off in (0, n // 2, n - 1):                                           # the last 4 bytes are the stored checksum
+            b = bytearray(blob)
+            b[pos + off] ^= 1 << int(rng.integers(0, 8))
+            open(p, 'wb').write(bytes(b))
+            with pytest.raises(Exception):
+                with H.File(p) as f:
+                    f['shuffled'][()]
+    m = H._Map(b'0123456789')
+    assert m[2:4] == b'23' and m[9] == ord('9') and len(m) == 10
+    for bad in (slice(8, 12), slice(-1, 3), slice(5, 2), slice(None, 11)):
+        with pytest.raises(ValueError):
+            m[bad]
+    with pytest.raises(ValueError):
+        m[10]
+    with pytest.raises(ValueError):
+        m[None:4] if False else m[slice('a', 4)]
