@@ -335,6 +335,30 @@ def split3_f32(x):
     return hx, lo
 
 
+def conv3x3_first_planes(xs, kernel_hwio, bias, precision):
+    """Kernel-level entry point of the first convolution of a 'bf16' (precision 1) / 'bf16x3' (2) model on the bf16 matrix
+    cores (include/dsen2_hip.h: dsen2_conv3x3_first_planes).  xs: the two or three NCHW float32 CUDA inputs (4 + 6 (+ 2)
+    bands); kernel_hwio (3, 3, 10 | 12, feat).  Returns the residual stream as the model holds it: precision 1 (hi, lo) int16
+    [n, feat/8, h, w, 8]; precision 2 (hx, lo16) with hx int16 [n, 2, feat/8, h, w, 8] (plane 0 = hi, plane 1 = xl)."""
+    kernel_hwio = np.ascontiguousarray(kernel_hwio, np.float32)
+    bias = np.ascontiguousarray(bias, np.float32)
+    feat = kernel_hwio.shape[3]
+    n, _, h, w = xs[0].shape
+    dev = xs[0].device
+    xs = [x.contiguous() for x in xs]
+    if precision == 2:
+        out = torch.empty((n, 2, feat // 8, h, w, 8), dtype=torch.int16, device=dev)
+    else:
+        out = torch.empty((n, feat // 8, h, w, 8), dtype=torch.int16, device=dev)
+    out2 = torch.empty((n, feat // 8, h, w, 8), dtype=torch.int16, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call('dsen2_conv3x3_first_planes', _ptr(xs[0]), _ptr(xs[1]), _ptr(xs[2]) if len(xs) == 3 else ctypes.c_void_p(0),
+                  xs[0].shape[1], xs[1].shape[1], xs[2].shape[1] if len(xs) == 3 else 0,
+                  kernel_hwio.ctypes.data_as(_lib.c_float_p), bias.ctypes.data_as(_lib.c_float_p), int(feat), int(precision),
+                  _ptr(out), _ptr(out2), n, h, w, _stream_ptr(dev))
+    return out, out2
+
+
 def conv3x3_body_bf16x3(x_planes, kernel_hwio, bias, epilogue=0, res_hx=None, res_lo=None, res_scale=RES_SCALE):
     """Kernel-level entry point of the bf16x3 body convolution.  x_planes: int16 (bf16 bit patterns) [n, 2, feat/8, h, w, 8].
     epilogue 0: returns relu(conv + bias) as such a two-plane tensor.  epilogue 1: updates the stream (res_hx, res_lo; see

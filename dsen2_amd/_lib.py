@@ -44,6 +44,8 @@ SIGNATURES = {
     'dsen2_join_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dsen2_conv3x3_body_bf16': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                         c_int, c_int, ctypes.c_float, c_void_p]),
+    'dsen2_conv3x3_first_planes': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float_p, c_float_p, c_int, c_int,
+                                           c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'dsen2_split3_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dsen2_conv3x3_body_bf16x3': (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_int, c_int, ctypes.c_float, c_void_p]),

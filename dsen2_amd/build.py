@@ -16,7 +16,7 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['conv3x3_body32.hip', 'conv3x3_body16w.hip', 'conv3x3_out.hip', 'conv3x3_out_mfma.hip', 'conv3x3_mfma.hip', 'conv3x3_first.hip', 'patch_ops.hip', 'capi.hip']
+SOURCES = ['conv3x3_body32.hip', 'conv3x3_body16w.hip', 'conv3x3_out.hip', 'conv3x3_out_mfma.hip', 'conv3x3_mfma.hip', 'conv3x3_first.hip', 'conv3x3_first16.hip', 'patch_ops.hip', 'capi.hip']
 HEADERS = [os.path.join(CSRC, "dsen2_internal.h"), os.path.join(CSRC, "conv3x3_dma.h"), os.path.join(CSRC, "conv3x3_bf16_common.h"), os.path.join(os.path.dirname(HERE), 'include', 'dsen2_hip.h')]
 LIB = os.path.join(HERE, 'libdsen2_hip.so')
 DIAG_LIB = os.path.join(os.path.dirname(HERE), 'build', 'libdsen2_hip_diag.so')

@@ -56,6 +56,7 @@ struct Layer {
   bool x3;              // ... as the (wh, wl, wh) planes of the bf16x3 form (precision 2): 3 x the bf16 weights
   PackGeom geom;
   size_t w_off, b_off;  // float offsets inside dev_params
+  size_t w16_off;       // first layer of a precision-1 / -2 model: its bf16 (wh | wl) form for conv3x3_first16.hip; 0 = none
   size_t flat_off;      // float offset of the kernel inside the keras-flat array
 };
 
@@ -223,6 +224,13 @@ static int model_create_unguarded(dsen2_model** out, int c10, int c20, int c60, 
     L.w_off = dev;
     dev += align_up(L.bf16 ? (size_t)9 * L.cin * L.cout / 2 : L.x3 ? (size_t)27 * L.cin * L.cout / 2 : packed_weight_floats(L.geom));
     L.b_off = dev; dev += align_up((size_t)L.geom.cout_pad);
+    // precision 1 / 2: the first convolution runs on the bf16 matrix cores (conv3x3_first16.hip) for the Sentinel-2 band
+    // groups 4 + 6 (+ 2); its fp32 form above stays for the generic fallback
+    L.w16_off = 0;
+    if (i == 0 && precision != 0 && num_layers > 0 && c10 == 4 && c20 == 6 && (c60 == 0 || c60 == 2)) {
+      L.w16_off = dev;
+      dev += align_up((first16_weight_u16(L.cout, precision == 2) + 1) / 2);
+    }
     m->layers.push_back(L);
   }
   m->n_params = flat;
@@ -265,6 +273,7 @@ static int model_load_weights_unguarded(dsen2_model* m, const float* host_flat, 
     else
       pack_conv_weights_host(k, L.cin, L.cout, L.geom, staged.data() + L.w_off);
     memcpy(staged.data() + L.b_off, b, sizeof(float) * L.cout);
+    if (L.w16_off) pack_first16_weights_host(k, L.cin, L.cout, m->precision == 2, reinterpret_cast<uint16_t*>(staged.data() + L.w16_off));
   }
   if (!m->dev_params) HIP_TRY(hipMalloc((void**)&m->dev_params, m->dev_param_floats * sizeof(float)));
   HIP_TRY(hipMemcpy(m->dev_params, staged.data(), m->dev_param_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -348,21 +357,27 @@ static int forward_impl(dsen2_model* m, const float* x10, const float* x20, cons
     // the default structure reads the NCHW inputs itself (conv3x3_first.hip); other channel counts, and the reference
     // structure (variant 0), pack them to NHWC16 first
     hipError_t direct = hipErrorNotSupported;
-    if (L.geom.variant == 10 || L.geom.variant == 12) {
+    const FirstInputs fi{x60, m->c10, m->c20, m->c60};
+    if (L.w16_off && (planes || x3)) {
+      // precision 1 / 2: on the bf16 matrix cores, writing the residual stream's planes itself (conv3x3_first16.hip) —
+      // precision 1: (hi, lo); precision 2: hx (hi | xl planes) and lo16
       ConvParams pd = pf;
       pd.in = x10;
       pd.aux = x20;
-      int epi_d = epi0;
-      if (x3) {            // precision 2: hx (hi | xl planes) and lo16 straight from the first convolution's epilogue
-        pd.out = t;
-        pd.out2 = t + ws_full;
-        epi_d = kEpiReluSplit3;
-      }
-      const FirstInputs fi{x60, m->c10, m->c20, m->c60};
-      direct = launch_conv3x3_first(pd, fi, m->feat, epi_d, stream, m->tune.first_ablate);
+      pd.wpk = P + L.w16_off;
+      pd.out = t;
+      pd.out2 = x3 ? t + ws_full : t + ws_half;
+      direct = launch_conv3x3_first16(pd, fi, m->feat, x3, stream);
+      if (direct != hipSuccess && direct != hipErrorNotSupported)
+        return fail(DSEN2_ERR_HIP, "first convolution (bf16 matrix cores) launch: %s", hipGetErrorString(direct));
+      x3_stream_written = x3 && direct == hipSuccess;
+    } else if (!planes && !x3 && (L.geom.variant == 10 || L.geom.variant == 12)) {
+      ConvParams pd = pf;
+      pd.in = x10;
+      pd.aux = x20;
+      direct = launch_conv3x3_first(pd, fi, m->feat, L.epilogue, stream, m->tune.first_ablate);
       if (direct != hipSuccess && direct != hipErrorNotSupported)
         return fail(DSEN2_ERR_HIP, "first convolution launch: %s", hipGetErrorString(direct));
-      x3_stream_written = x3 && direct == hipSuccess;
     }
     if (direct != hipSuccess) {
       HIP_TRY(launch_pack_inputs(x10, x20, x60, m->c10, m->c20, m->c60, x0, n, h, w, stream));
@@ -659,6 +674,38 @@ static int conv3x3_body_bf16x3_unguarded(const void* dev_in_planes, const float*
   return DSEN2_OK;
 }
 
+static int conv3x3_first_planes_unguarded(const float* dev_x10, const float* dev_x20, const float* dev_x60, int c10, int c20, int c60,
+                                          const float* host_kernel, const float* host_bias, int feat, int precision,
+                                          void* dev_out, void* dev_out2, int n, int h, int w, void* stream_) {
+  if (!dev_x10 || !dev_x20 || !host_kernel || !host_bias || !dev_out || !dev_out2) return fail(DSEN2_ERR_INVALID, "NULL argument");
+  if ((c60 > 0) != (dev_x60 != nullptr)) return fail(DSEN2_ERR_INVALID, "dev_x60 must be given iff c60 > 0");
+  if (feat != 128 && feat != 256) return fail(DSEN2_ERR_INVALID, "feat %d unsupported", feat);
+  if (precision != 1 && precision != 2) return fail(DSEN2_ERR_INVALID, "precision %d (1 = bf16 operands, 2 = bf16x3)", precision);
+  if (c10 != 4 || c20 != 6 || (c60 != 0 && c60 != 2)) return fail(DSEN2_ERR_INVALID, "band groups %d + %d + %d (4 + 6 (+ 2) only)", c10, c20, c60);
+  int rc = check_shape(nullptr, n, h, w);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool x3 = precision == 2;
+  const int cin = c10 + c20 + c60;
+  const size_t wn = first16_weight_u16(feat, x3);
+  std::vector<uint16_t> wb(wn);
+  pack_first16_weights_host(host_kernel, cin, feat, x3, wb.data());
+  char* dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev, wn * 2 + feat * sizeof(float)));
+  hipError_t e = hipMemcpy(dev, wb.data(), wn * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dev + wn * 2, host_bias, feat * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    ConvParams p = make_params(dev_x10, reinterpret_cast<const float*>(dev), reinterpret_cast<const float*>(dev + wn * 2), dev_x20,
+                               reinterpret_cast<float*>(dev_out), n, h, w, 0, 0.f);
+    p.out2 = dev_out2;
+    e = launch_conv3x3_first16(p, FirstInputs{dev_x60, c10, c20, c60}, feat, x3, stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(DSEN2_ERR_HIP, "first convolution (bf16 matrix cores) launch: %s", hipGetErrorString(e));
+  return DSEN2_OK;
+}
+
 static int conv3x3_body_bf16_unguarded(const void* dev_in_bf16, const float* host_kernel, const float* host_bias, void* dev_res_hi,
                             void* dev_res_lo, void* dev_out, int n, int h, int w, int feat, int epilogue,
                             float res_scale, void* stream_) {
@@ -830,6 +877,9 @@ int dsen2_split3_f32(const float* dev_in, void* dev_hx, void* dev_lo, int n, int
 }
 int dsen2_conv3x3_body_bf16x3(const void* dev_in_planes, const float* host_kernel, const float* host_bias, void* dev_res_hx, void* dev_res_lo, void* dev_out, int n, int h, int w, int feat, int epilogue, float res_scale, void* stream) {
   return guarded([&] { return conv3x3_body_bf16x3_unguarded(dev_in_planes, host_kernel, host_bias, dev_res_hx, dev_res_lo, dev_out, n, h, w, feat, epilogue, res_scale, stream); });
+}
+int dsen2_conv3x3_first_planes(const float* dev_x10, const float* dev_x20, const float* dev_x60, int c10, int c20, int c60, const float* host_kernel, const float* host_bias, int feat, int precision, void* dev_out, void* dev_out2, int n, int h, int w, void* stream) {
+  return guarded([&] { return conv3x3_first_planes_unguarded(dev_x10, dev_x20, dev_x60, c10, c20, c60, host_kernel, host_bias, feat, precision, dev_out, dev_out2, n, h, w, stream); });
 }
 int dsen2_conv3x3_body_bf16(const void* dev_in_bf16, const float* host_kernel, const float* host_bias, void* dev_res_hi, void* dev_res_lo, void* dev_out, int n, int h, int w, int feat, int epilogue, float res_scale, void* stream_) {
   return guarded([&] { return conv3x3_body_bf16_unguarded(dev_in_bf16, host_kernel, host_bias, dev_res_hi, dev_res_lo, dev_out, n, h, w, feat, epilogue, res_scale, stream_); });

@@ -1,6 +1,6 @@
 // conv3x3_first.hip — the network's FIRST convolution (utils/DSen2Net.py:24-29): Concatenate(axis=1) of the two or
-// three NCHW inputs, Conv2D(F, 3x3, 'same') + bias + ReLU -> NHWC fp32 (or, for a precision-1 model, the blocked
-// (hi, lo) planes of the residual stream).
+// three NCHW inputs, Conv2D(F, 3x3, 'same') + bias + ReLU -> NHWC fp32, exact fp32 arithmetic (precision 0).  The bf16-operand
+// modes run this layer on the bf16 matrix cores and write the residual stream's planes: conv3x3_first16.hip.
 //
 // Round 2 ran this layer as pack_inputs_kernel (NCHW -> NHWC16, a 54 MB round trip) + conv3x3_mfma_kernel<16, 16, ...>:
 // one 16x16-pixel tile per workgroup, the 72 KB of weights streamed from L2 for EVERY tile with a barrier per tap.
@@ -46,8 +46,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 }  // namespace
 
 // CREAL: real input channels (10 = 4 + 6 or 12 = 4 + 6 + 2; c10 + c20 + c60 must equal it).  EPI: kEpiRelu (p.out fp32
-// NHWC), kEpiReluSplit (p.out / p.out2: blocked (hi, lo) planes) or kEpiReluSplit3 (p.out: hi | xl planes, p.out2: lo16).  p.in = x10, p.aux = x20, p.diag unused; x60 and the
-// channel counts come in `f`.
+// NHWC).  p.in = x10, p.aux = x20, p.diag unused; x60 and the channel counts come in `f`.
 // ABL (diagnostic builds, timing only): 1 no stores, 2 no MFMAs, 4 no input gather.
 template <int CREAL, int COUT, int EPI, int ABL = 0>
 __global__ __launch_bounds__(first::THREADS, 2) void conv3x3_first_kernel(const ConvParams p, const FirstInputs f, const int n_items) {
@@ -179,29 +178,9 @@ __global__ __launch_bounds__(first::THREADS, 2) void conv3x3_first_kernel(const 
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       if constexpr ((ABL & 1) != 0) {
         asm volatile("" ::"v"(v));
-      } else if constexpr (EPI == kEpiRelu) {
-        *reinterpret_cast<f32x4*>(p.out + pix * COUT + c0) = v;
       } else {
-        // blocked (hi, lo) planes [n][C/8][h][w][8] (conv3x3_body16w.hip): this lane's 4 channels are bytes
-        // 8*hsel .. 8*hsel+7 of the pixel's 16-byte piece in block c0 >> 3; lanes l and l + 32 complete it
-        unsigned h01, l01, h23, l23;
-        bf16k::split2(__float_as_uint(v[0]), __float_as_uint(v[1]), h01, l01);
-        bf16k::split2(__float_as_uint(v[2]), __float_as_uint(v[3]), h23, l23);
-        const size_t off = (((size_t)t.img * (COUT / 8) + (c0 >> 3)) * img_pix + (size_t)y * p.w + x) * 16 + (c0 & 7) * 2;
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        if constexpr (EPI == kEpiReluSplit3) {
-          // precision 2: p.out has TWO planes per image (hi | xl = bf16(x - hi), the convolutions' operand pair), p.out2 the
-          // low halves — what launch_split3_f32 makes of an fp32 tensor (conv3x3_body16w.hip, X3)
-          const size_t off_hi = off + (size_t)t.img * (COUT / 8) * img_pix * 16;
-          const unsigned x01 = bf16k::pack_bf16(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
-          const unsigned x23 = bf16k::pack_bf16(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
-          *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) + off_hi) = u32x2{h01, h23};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) + off_hi + (size_t)(COUT / 8) * img_pix * 16) = u32x2{x01, x23};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + off) = u32x2{l01, l23};
-        } else {
-        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) + off) = u32x2{h01, h23};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + off) = u32x2{l01, l23};
-        }
+        static_assert(EPI == kEpiRelu, "fp32 NHWC output only: the plane-writing forms are conv3x3_first16.hip's");
+        *reinterpret_cast<f32x4*>(p.out + pix * COUT + c0) = v;
       }
     }
   };
@@ -311,20 +290,17 @@ static hipError_t launch_first_one(const ConvParams& p, const FirstInputs& f, hi
 }
 
 // p.in = x10, p.aux = x20 (NCHW), p.wpk / p.bias: weights packed with PackGeom{16, 128, 16, cout, .}; p.out NHWC fp32
-// (kEpiRelu) or p.out / p.out2 = the blocked (hi, lo) planes (kEpiReluSplit).  hipErrorNotSupported: channel counts
+// (kEpiRelu only).  hipErrorNotSupported: channel counts
 // other than 10 / 12 (the generic pack_inputs + conv3x3_mfma path handles those).
 hipError_t launch_conv3x3_first(const ConvParams& p, const FirstInputs& f, int cout, int epilogue, hipStream_t stream, int ablate) {
   const int creal = f.c10 + f.c20 + f.c60;
   if (f.c10 != 4 || f.c20 != 6 || (f.c60 != 0 && f.c60 != 2)) return hipErrorNotSupported;      // the Sentinel-2 band groups
   if ((size_t)p.h * p.w * 6 * 4 >= ((size_t)1 << 31)) return hipErrorNotSupported;               // 32-bit offsets inside one image
-  if (!p.in || !p.aux || (f.c60 > 0 && !f.x60) || !p.out || (epilogue != kEpiRelu && !p.out2)) return hipErrorInvalidValue;
+  if (!p.in || !p.aux || (f.c60 > 0 && !f.x60) || !p.out) return hipErrorInvalidValue;
   if ((size_t)p.h * p.w * (size_t)cout * 4 >= ((size_t)1 << 40)) return hipErrorInvalidValue;
-#define DSEN2_FIRST(CR, CO)                                                                                 \
-  if (creal == CR && cout == CO)                                                                            \
-    return epilogue == kEpiRelu        ? launch_first_one<CR, CO, kEpiRelu>(p, f, stream)                   \
-           : epilogue == kEpiReluSplit ? launch_first_one<CR, CO, kEpiReluSplit>(p, f, stream)              \
-                                       : launch_first_one<CR, CO, kEpiReluSplit3>(p, f, stream);
-  if (epilogue != kEpiRelu && epilogue != kEpiReluSplit && epilogue != kEpiReluSplit3) return hipErrorInvalidValue;
+#define DSEN2_FIRST(CR, CO) \
+  if (creal == CR && cout == CO) return launch_first_one<CR, CO, kEpiRelu>(p, f, stream);
+  if (epilogue != kEpiRelu) return hipErrorInvalidValue;      // the (hi, lo) / (hi | xl, lo16) plane forms: conv3x3_first16.hip
 #ifdef DSEN2_DIAG
   if (creal == 10 && cout == 128 && epilogue == kEpiRelu) {
     if (ablate == 1) return launch_first_one<10, 128, kEpiRelu, 1>(p, f, stream);

@@ -104,12 +104,18 @@ void pack_out_valu_weights_host(const float* kernel_hwio, int cin, int cout, flo
 hipError_t launch_conv3x3_out_mfma(const ConvParams& p, int feat, hipStream_t stream, bool* taken, int ablate = 0);
 size_t out_mfma_weight_floats(int cin);
 void pack_out_mfma_weights_host(const float* kernel_hwio, int cin, int cout, float* dst);
-// First convolution reading the NCHW inputs directly (conv3x3_first.hip): p.in = x10, p.aux = x20; weights packed with
-// PackGeom{16, 128, 16, cout, .}; epilogue kEpiRelu (p.out fp32 NHWC), kEpiReluSplit (p.out / p.out2 = (hi, lo) planes) or
-// kEpiReluSplit3 (p.out = hi | xl planes, p.out2 = lo16: launch_split3_f32's tensors).
+// First convolution reading the NCHW inputs directly (conv3x3_first.hip, exact fp32): p.in = x10, p.aux = x20; weights packed
+// with PackGeom{16, 128, 16, cout, .}; epilogue kEpiRelu only (p.out fp32 NHWC).
 // hipErrorNotSupported for channel counts other than 10 / 12 (then: launch_pack_inputs + launch_conv3x3).
 struct FirstInputs { const float* x60; int c10, c20, c60; };
 hipError_t launch_conv3x3_first(const ConvParams& p, const FirstInputs& f, int cout, int epilogue, hipStream_t stream, int ablate = 0);
+// ... of a precision-1 / -2 model, on the bf16 matrix cores (conv3x3_first16.hip): same inputs; p.wpk = the buffer
+// pack_first16_weights_host fills (first16_weight_u16(cout, x3) uint16); x3 = false: p.out / p.out2 = the blocked (hi, lo)
+// planes of the residual stream (bf16 operands: out = relu(bf16(x) * bf16(w) + b)); x3 = true: p.out = hx (hi | xl planes),
+// p.out2 = lo16 — launch_split3_f32's tensors — with three-MFMA products (xh*wh + xh*wl + xl*wh).  hipErrorNotSupported as above.
+hipError_t launch_conv3x3_first16(const ConvParams& p, const FirstInputs& f, int cout, bool x3, hipStream_t stream);
+size_t first16_weight_u16(int cout, bool x3);
+void pack_first16_weights_host(const float* kernel_hwio, int cin, int cout, bool x3, uint16_t* dst);
 // DMA-fed fp32 kernel (conv3x3_body32.hip): F = 128 or 256, images < 2 GiB; weights packed with KC=32, NT=128
 bool body32_supports(const ConvParams& p, int cout);
 hipError_t launch_conv3x3_body32(const ConvParams& p, int feat, int epilogue, int sub, int ablate, hipStream_t stream);

@@ -173,6 +173,18 @@ int dsen2_conv3x3_body_bf16x3(const void *dev_in_planes, const float *host_kerne
                               void *dev_res_hx, void *dev_res_lo, void *dev_out, int n, int h, int w, int feat,
                               int epilogue, float res_scale, void *stream);
 
+/* The FIRST convolution of a precision-1 / -2 model at kernel level (utils/DSen2Net.py:24-29: Concatenate(axis=1) of the
+ * NCHW inputs + Conv2D(feat, 3x3, 'same') + bias + ReLU) on the bf16 matrix cores, writing the residual stream in the form the
+ * residual-block kernels read.  Band groups 4 + 6 (+ 2) only; host_kernel HWIO (3, 3, c10 + c20 + c60, feat).
+ *   precision 1: out = relu(sum bf16(x) * bf16(w) + bias) (RNE roundings, fp32 accumulate);
+ *                dev_out / dev_out2 = its blocked (hi, lo) planes — dsen2_split_f32's tensors
+ *   precision 2: x = xh + xl, w = wh + wl (bf16 each), products xh*wh + xh*wl + xl*wh in fp32;
+ *                dev_out = hx (two planes per image: hi | xl), dev_out2 = lo16 — dsen2_split3_f32's tensors
+ * Test path (packs on every call, synchronises). */
+int dsen2_conv3x3_first_planes(const float *dev_x10, const float *dev_x20, const float *dev_x60, int c10, int c20, int c60,
+                               const float *host_kernel, const float *host_bias, int feat, int precision,
+                               void *dev_out, void *dev_out2, int n, int h, int w, void *stream);
+
 /* Body-convolution micro-benchmark hook: runs `iters` launches of the 128->128 (or F->F) kernel on
  * caller-provided NHWC buffers with already-packed weights held by `m` (layer index `layer`, 1-based
  * body conv number), after 24 untimed launches of the same kernel (the chip's clock after an idle stretch), and reports the

@@ -173,10 +173,10 @@ def test_bf16_zero_weights_return_skip_input_exactly_and_full_batch_f128():
 @pytest.mark.parametrize('d,feat,n,h,w', [(2, 128, 2, 32, 32), (1, 256, 1, 21, 37), (3, 128, 1, 16, 33)])
 def test_precision1_forward_is_the_chain_of_its_kernel_level_operations(d, feat, n, h, w):
     """dsen2_model_forward with precision 1 against the same network assembled from the kernel-level entry points
-    (first convolution in fp32 -> dsen2_split_f32 -> bf16 conv-A / conv-B on the planes -> fp32 output convolution):
-    bit for bit.  Pins what the forward fuses — the first convolution writing the (hi, lo) planes itself
-    (kEpiReluSplit), the in-place plane updates, the last block's fp32 form — to operations tested on their own."""
-    from dsen2_amd.DSen2Net import (conv3x3_body_bf16, conv3x3_nhwc, from_blocked, s2model, split_f32)
+    (first convolution on the bf16 matrix cores writing the (hi, lo) planes, dsen2_conv3x3_first_planes -> bf16 conv-A /
+    conv-B on the planes -> fp32 output convolution): bit for bit.  Pins what the forward strings together — the in-place
+    plane updates, the last block's fp32 form — to operations tested on their own (the first one: test_gpu_first16.py)."""
+    from dsen2_amd.DSen2Net import (conv3x3_body_bf16, conv3x3_first_planes, conv3x3_nhwc, from_blocked, s2model)
     flat = do.he_uniform_weights(10, 6, d, feat, seed=d + feat, bias_scale=0.05)
     xs = do.synthetic_inputs(n, h, w, (4, 6), seed=3)
     m = s2model(((4, None, None), (6, None, None)), num_layers=d, feature_size=feat, precision='bf16')
@@ -184,14 +184,7 @@ def test_precision1_forward_is_the_chain_of_its_kernel_level_operations(d, feat,
     xd = [torch.from_numpy(a).cuda() for a in xs]
     y = m.forward_device(xd)
     layers = do.split_weights(np.asarray(flat), 10, 6, d, feat)
-    # first convolution on the 16-channel packed input (zero channels and zero kernel rows add exact zeros)
-    x0 = torch.zeros((n, h, w, 16), dtype=torch.float32, device='cuda')
-    x0[..., :4] = xd[0].permute(0, 2, 3, 1)
-    x0[..., 4:10] = xd[1].permute(0, 2, 3, 1)
-    k0 = np.zeros((3, 3, 16, feat), np.float32)
-    k0[:, :, :10] = layers[0][0]
-    a = conv3x3_nhwc(x0, k0, layers[0][1], epilogue=0)
-    hi, lo = split_f32(a)
+    hi, lo = conv3x3_first_planes(xd, layers[0][0], layers[0][1], precision=1)
     for i in range(d):
         (ka, ba), (kb, bb) = layers[1 + 2 * i], layers[2 + 2 * i]
         t = conv3x3_body_bf16(from_blocked(hi.view(torch.bfloat16)), ka, ba, epilogue=0)

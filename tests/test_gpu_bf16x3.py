@@ -187,10 +187,10 @@ def test_bf16x3_dsen2_60_on_a_whole_bundled_tile(golden_dir, tmp_path, monkeypat
 @pytest.mark.parametrize('d,feat,n,h,w', [(2, 128, 2, 32, 32), (1, 256, 1, 21, 37), (3, 128, 1, 16, 33)])
 def test_precision2_forward_is_the_chain_of_its_kernel_level_operations(d, feat, n, h, w):
     """dsen2_model_forward with precision 2 against the same network assembled from the kernel-level entry points (first
-    convolution in fp32 -> dsen2_split3_f32 -> bf16x3 conv-A / conv-B on the planes -> fp32 output convolution): bit for bit.
-    Pins what the forward fuses — the first convolution writing the stream's three planes itself (kEpiReluSplit3), the
-    in-place updates, the last block's fp32 form — to operations tested on their own."""
-    from dsen2_amd.DSen2Net import conv3x3_body_bf16x3, conv3x3_nhwc, s2model, split3_f32
+    convolution in bf16x3 on the matrix cores writing the stream's three planes, dsen2_conv3x3_first_planes -> bf16x3 conv-A /
+    conv-B on the planes -> fp32 output convolution): bit for bit.  Pins what the forward strings together — the in-place
+    updates, the last block's fp32 form — to operations tested on their own (the first one: test_gpu_first16.py)."""
+    from dsen2_amd.DSen2Net import conv3x3_body_bf16x3, conv3x3_first_planes, conv3x3_nhwc, s2model
     flat = do.he_uniform_weights(10, 6, d, feat, seed=d + feat, bias_scale=0.05)
     xs = do.synthetic_inputs(n, h, w, (4, 6), seed=3)
     m = s2model(((4, None, None), (6, None, None)), num_layers=d, feature_size=feat, precision='bf16x3')
@@ -198,13 +198,7 @@ def test_precision2_forward_is_the_chain_of_its_kernel_level_operations(d, feat,
     xd = [torch.from_numpy(a).cuda() for a in xs]
     y = m.forward_device(xd)
     layers = do.split_weights(np.asarray(flat), 10, 6, d, feat)
-    x0 = torch.zeros((n, h, w, 16), dtype=torch.float32, device='cuda')
-    x0[..., :4] = xd[0].permute(0, 2, 3, 1)
-    x0[..., 4:10] = xd[1].permute(0, 2, 3, 1)
-    k0 = np.zeros((3, 3, 16, feat), np.float32)
-    k0[:, :, :10] = layers[0][0]
-    a = conv3x3_nhwc(x0, k0, layers[0][1], epilogue=0)
-    hx, lo = split3_f32(a)
+    hx, lo = conv3x3_first_planes(xd, layers[0][0], layers[0][1], precision=2)
     for i in range(d):
         (ka, ba), (kb, bb) = layers[1 + 2 * i], layers[2 + 2 * i]
         t = conv3x3_body_bf16x3(hx, ka, ba, epilogue=0)
