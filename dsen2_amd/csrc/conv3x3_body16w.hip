@@ -2,7 +2,7 @@
 // (utils/DSen2Net.py:9-15 with precision = 1): v_mfma_f32_16x16x32_bf16 fed by LDS-DMA, WIDE pixel tile.
 //
 // Round-1's kernel (16x16 pixels x 128 channels per item) spent its time in the CU's vector-memory path, not
-// in the matrix pipe (profiles/r01_ablation.md): per 151 MFLOP item it pulled 576 KiB of weights + 162 KiB of
+// in the matrix pipe (profiles/archive/r01_ablation.md): per 151 MFLOP item it pulled 576 KiB of weights + 162 KiB of
 // input through L1 into LDS and, for conv-B, pushed 24 store instructions per lane back through the same path.
 // This kernel changes the three ratios that set that traffic:
 //
@@ -16,7 +16,7 @@
 //      (vmcnt(63)): the stores get 2.5 us to drain instead of one step.
 //      The nine taps of a chunk are walked DX-MAJOR: the ten 16-pixel row fragments (8 rows + 2 halo rows) of one dx
 //      stay in registers for its three dy taps — 22 ds_read_b128 per 96 MFMAs (round 1: 48, tap-major: 36).  The
-//      board runs this kernel at its power cap, so LDS bytes saved are clock gained (profiles/r02_h_power.md).
+//      board runs this kernel at its power cap, so LDS bytes saved are clock gained (profiles/archive/r02_h_power.md).
 //      The workgroup synchronises after steps 1, 3, 5, 7, 8 of a chunk only (barrier_after below).
 //   3. RESIDUAL STREAM AS TWO 16-BIT PLANES (conv-B).  The fp32 residual value u is kept as
 //      hi = (u + 0x8000) >> 16 (its bf16 rounding, ties away from zero) and lo = u & 0xffff: the pair restores u bit

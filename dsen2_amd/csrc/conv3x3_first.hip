@@ -16,7 +16,7 @@
 //   * DEFERS its epilogue like the body kernel: a finished tile's accumulators are copied to a second register set and
 //     written out two 16-byte pieces per tap inside the NEXT tile's tap loop, so the 128 KB of stores per tile leave
 //     under MFMAs instead of in a phase of their own (measured before: MFMA loop alone 97 us, stores alone 47 us, the
-//     two in sequence 126 us — profiles/r03_d_first_conv_ablation.log).
+//     two in sequence 126 us — profiles/archive/r03_d_first_conv_ablation.log).
 // The MFMA sequence per accumulator is exactly conv3x3_mfma_kernel's first-layer form (per tap: channels (j, 4 + j) for
 // j = 0..3, then the pairs (8, 9)(, (10, 11)); taps in order), so every output bit is the same
 // (tests/test_gpu_forward.py::test_first_layer_without_padding_mfmas_gives_the_same_bits pins it against the generic kernel).

@@ -19,7 +19,7 @@
 //     how the image was cut into strips or blocks.
 // A workgroup takes whole images (or strips of rows with one recomputed row above and below when there are few images).
 // Bench config (512 x 32 x 32, F = 128, Cout 6): 79 us against 121 on the vector units; FETCH_SIZE = the algorithmic 281 MB.
-// What bounds it and what was tried: profiles/r03_ablation.md §4, HISTORY.md §3.2.
+// What bounds it and what was tried: profiles/archive/r03_ablation.md §4, HISTORY.md §3.2.
 #include "dsen2_internal.h"
 
 namespace dsen2 {

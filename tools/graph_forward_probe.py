@@ -1,5 +1,5 @@
 """The whole forward replayed as ONE hipGraph (torch.cuda.CUDAGraph around dsen2_model_forward) against plain
-launches: same bits, no gain (profiles/r02_ablation.md §3) — the launches are not host-bound.
+launches: same bits, no gain (profiles/archive/r02_ablation.md §3) — the launches are not host-bound.
     python tools/graph_forward_probe.py"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Samples the GPU's power, power cap and shader clock from sysfs (hwmon) while a bench.py run keeps one kernel family
-busy — evidence for HISTORY.md §3.2b / profiles/r02_ablation.md §2 (is the bf16 body convolution power-limited?).
+busy — evidence for HISTORY.md §3.2b / profiles/archive/r02_ablation.md §2 (is the bf16 body convolution power-limited?).
 
     python tools/power_probe.py [config ...]          # default: dsen2_20_fp32 vdsen2_20_bf16
     python tools/power_probe.py --mfma                # build/mfma_peak (tools/mfma_peak.hip): the bare matrix pipe

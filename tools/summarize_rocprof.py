@@ -2,7 +2,7 @@
 """Turn a rocprofv3 `--kernel-trace --stats --output-format csv` directory into a short markdown summary
 (kernel names truncated) suitable for committing under profiles/.
 
-    python tools/summarize_rocprof.py gpurun_out/prof1 profiles/r01_bench_kernel_stats.md "command line"
+    python tools/summarize_rocprof.py gpurun_out/prof1 profiles/archive/r01_bench_kernel_stats.md "command line"
 """
 import csv
 import glob
