@@ -39,12 +39,14 @@ def needs_build(lib=LIB):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, diag=False):
-    lib = DIAG_LIB if diag else LIB
-    if not force and not needs_build(lib):
+def build(force=False, verbose=False, diag=False, variant=None, extra_flags=()):
+    """variant = NAME (tools/ only): build/lib_NAME.so from the same sources with `extra_flags` (-D switches of single
+    translation units, for same-box A/B runs through DSEN2_HIP_LIB); never the product library, no ISA contract check."""
+    lib = os.path.join(os.path.dirname(DIAG_LIB), 'lib_%s.so' % variant) if variant else DIAG_LIB if diag else LIB
+    if not force and not variant and not needs_build(lib):
         return lib
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    flags = FLAGS + (['-DDSEN2_DIAG'] if diag else [])
+    flags = FLAGS + (['-DDSEN2_DIAG'] if diag else []) + list(extra_flags)
     # one hipcc process per translation unit (objects in a scratch directory, nothing but the .so is left in-tree)
     with tempfile.TemporaryDirectory(prefix='dsen2_build_') as tmp:
         def compile_one(src):
@@ -60,7 +62,7 @@ def build(force=False, verbose=False, diag=False):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-        if not diag:
+        if not diag and not variant:
             from . import asm_contract
             try:
                 asm_contract.check_sources(HIPCC, FLAGS, verbose=verbose, isa_json=asm_contract.ISA_JSON)
@@ -72,4 +74,8 @@ def build(force=False, verbose=False, diag=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True, diag='--diag' in sys.argv))
+    if '--variant' in sys.argv:        # python -m dsen2_amd.build --variant NAME -DFOO=1 ...
+        i = sys.argv.index('--variant')
+        print(build(force=True, verbose=True, variant=sys.argv[i + 1], extra_flags=[a for a in sys.argv[i + 2:] if a.startswith('-D')]))
+    else:
+        print(build(force='--force' in sys.argv, verbose=True, diag='--diag' in sys.argv))

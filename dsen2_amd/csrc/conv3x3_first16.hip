@@ -31,6 +31,13 @@
 #include "conv3x3_bf16_common.h"
 #include "dsen2_internal.h"
 
+// Compile-time switches of VARIANT builds only (python -m dsen2_amd.build --variant NAME -D...; tools/ab_first16.sh): the
+// product is built with the default.  FIRST16_ABL = timing-only ablation mask (1 no stores, 2 no MFMAs, 4 no input gather;
+// outputs are wrong).
+#ifndef FIRST16_ABL
+#define FIRST16_ABL 0
+#endif
+
 namespace dsen2 {
 
 namespace {
@@ -102,7 +109,9 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
 
   // ---- gather geometry of one halo tile (conv3x3_first.hip's): per input tensor its CT x 324 values in rounds of 512
   // threads, channel outer / halo pixel inner.  pk = hx | hy << 5 | (channel inside its tensor) << 10 | (LDS bf16 index of
-  // the value inside a plane) << 13, negative = no element ----
+  // the value inside a plane) << 13 | (no element) << 30.  A lane without an element still loads (out of range: zero) and
+  // still writes — into the padding slots 16-23 of a halo pixel, which no operand read covers — so that the loop body has NO
+  // divergent branch: hipcc then counts the vector-memory operations in flight exactly (see the waits below) ----
   constexpr int C10 = 4, C20 = 6, C60 = CREAL - 10;
   constexpr int R10 = (C10 * kHaloPix + THREADS - 1) / THREADS, R20 = (C20 * kHaloPix + THREADS - 1) / THREADS,
                 R60 = (C60 * kHaloPix + THREADS - 1) / THREADS;
@@ -116,7 +125,8 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
         const int c = e / kHaloPix, hp = e - c * kHaloPix;
         const int hy = hp / kHalo, hx = hp - hy * kHalo;
         const bool have = e < ct * kHaloPix;
-        pk[r0 + r] = have ? hx | hy << 5 | c << 10 | (hp * PITCH + cbase + c) << 13 : -1;
+        pk[r0 + r] = have ? hx | hy << 5 | c << 10 | (hp * PITCH + cbase + c) << 13
+                          : (hp * PITCH + KSLOTS + (c & 7)) << 13 | 1 << 30;
       }
     };
     setup(0, R10, C10, 0);
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
         int k = pk[r0 + r];
         asm volatile("" : "+v"(k));      // derive the addresses here, every tile: hoisted out of the item loop they are spilled
         const int gy = t.ty0 - 1 + ((k >> 5) & 31), gx = t.tx0 - 1 + (k & 31);
-        const bool inb = k >= 0 && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
+        const bool inb = (k >> 30) == 0 && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w;
         const unsigned voff = inb ? (unsigned)((((k >> 10) & 7) * (int)plane + gy * p.w + gx) * 4) : 0x80000000u;
         v[r0 + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, 0, 0));
       }
@@ -152,13 +162,12 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
   // fp32 -> bf16 (RNE; precision 2: also the remainder's bf16) into one input buffer (PL planes, IN_PLANE_BYTES apart)
   auto scatter = [&](char* buf, const float (&v)[ROUNDS]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r)
-      if (pk[r] >= 0) {
-        const __bf16 xh = (__bf16)v[r];
-        __bf16* const dst = reinterpret_cast<__bf16*>(buf) + (pk[r] >> 13);
-        dst[0] = xh;
-        if constexpr (X3) dst[IN_PLANE_BYTES / 2] = (__bf16)(v[r] - (float)xh);
-      }
+    for (int r = 0; r < ROUNDS; ++r) {
+      const __bf16 xh = (__bf16)v[r];
+      __bf16* const dst = reinterpret_cast<__bf16*>(buf) + ((pk[r] >> 13) & 0x1fff);
+      dst[0] = xh;
+      if constexpr (X3) dst[IN_PLANE_BYTES / 2] = (__bf16)(v[r] - (float)xh);
+    }
   };
 
   // ---- per-lane operand byte offsets ----
@@ -176,43 +185,77 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
   __syncthreads();
 
   const size_t img_pix = plane;
-  // one 16-byte piece of a finished tile: register quad g of accumulator (mb, pb) = channels 8g + 4*hsel .. +3 of one pixel;
-  // j = 8*pb + 4*mb + g.  Blocked planes [n][C/8][h][w][8] (conv3x3_body16w.hip): this lane's 4 channels are bytes
-  // 8*hsel .. 8*hsel+7 of the pixel's 16-byte piece in block c0 >> 3; lanes l and l + 32 complete it.
-  auto store_piece = [&](int j, const f32x16 (&h)[MB][PB], const Tile& t, bool valid) __attribute__((always_inline)) {
-    const int pb = j >> 3, mb = (j >> 2) & 1, g = j & 3;
+  // Two 16-byte pieces of a finished tile (register quads g0 = even and g0 + 1 of one accumulator (mb, pb); tp = 4*pb + 2*mb
+  // + g0/2) as ONE 16-byte store per lane and plane.  A lane holds 4 of a pixel's 8 channels of a block (quad g = channels 8g +
+  // 4*hsel .. + 3), lane ^ 32 the other 4: v_permlane32_swap exchanges quad g0 of the upper half-wave with quad g0 + 1 of the
+  // lower one, after which lanes 0-31 own the whole piece of block g0 and lanes 32-63 that of block g0 + 1 (blocked planes
+  // [n][C/8][h][w][8], conv3x3_body16w.hip).  The stores go through per-IMAGE buffer descriptors (`so`: one per plane tensor)
+  // and are issued by EVERY lane, always: a lane without a pixel (ragged tile edge, or the dummy pass before the first tile)
+  // stores at an out-of-range offset, which the hardware drops — no divergent branch in the loop body.
+  struct StoreRsrc { __amdgpu_buffer_rsrc_t out, out2; };
+  auto store_rsrc = [&](const Tile& t) __attribute__((always_inline)) -> StoreRsrc {
+    const size_t plane_bytes = (size_t)(COUT / 8) * img_pix * 16;      // one image, one plane: < 2^31 (launcher)
+    const int img = __builtin_amdgcn_readfirstlane(t.img);
+    return StoreRsrc{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (size_t)img * PL * plane_bytes, 0,
+                                                       (unsigned)(PL * plane_bytes), 0x00020000),
+                     __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out2) + (size_t)img * plane_bytes, 0,
+                                                       (unsigned)plane_bytes, 0x00020000)};
+  };
+  auto store_pair = [&](int tp, const f32x16 (&h)[MB][PB], const Tile& t, const StoreRsrc& so, bool valid) __attribute__((always_inline)) {
+    const int j0 = 2 * tp;
+    const int pb = j0 >> 3, mb = (j0 >> 2) & 1, g0 = j0 & 3;
     const int blk = wp * PB + pb;
     const int y = t.ty0 + 2 * blk + (l31 >> 4);
     const int x = t.tx0 + (l31 & 15);
-    if (valid && y < p.h && x < p.w) {
-      const int c0 = slab * NT + wn * (32 * MB) + mb * 32 + 8 * g + 4 * hsel;
+    unsigned hh[2][2], ll[2][2], xx[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int g = g0 + q;
+      const int cl = wn * (32 * MB) + mb * 32 + 8 * g + 4 * hsel;       // channel inside the slab
       f32x4 v = {h[mb][pb][4 * g], h[mb][pb][4 * g + 1], h[mb][pb][4 * g + 2], h[mb][pb][4 * g + 3]};
-      v += *reinterpret_cast<const f32x4*>(bias_s + c0 - slab * NT);
+      v += *reinterpret_cast<const f32x4*>(bias_s + cl);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      unsigned h01, l01, h23, l23;
-      bf16k::split2(__float_as_uint(v[0]), __float_as_uint(v[1]), h01, l01);
-      bf16k::split2(__float_as_uint(v[2]), __float_as_uint(v[3]), h23, l23);
-      const size_t off = (((size_t)t.img * (COUT / 8) + (c0 >> 3)) * img_pix + (size_t)y * p.w + x) * 16 + (c0 & 7) * 2;
-      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      bf16k::split2(__float_as_uint(v[0]), __float_as_uint(v[1]), hh[q][0], ll[q][0]);
+      bf16k::split2(__float_as_uint(v[2]), __float_as_uint(v[3]), hh[q][1], ll[q][1]);
       if constexpr (X3) {
-        // p.out has TWO planes per image (hi | xl = bf16(x - hi), the convolutions' operand pair), p.out2 the low halves —
-        // what launch_split3_f32 makes of an fp32 tensor
-        const size_t off_hi = off + (size_t)t.img * (COUT / 8) * img_pix * 16;
-        const unsigned x01 = bf16k::pack_bf16(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u));
-        const unsigned x23 = bf16k::pack_bf16(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u));
-        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) + off_hi) = u32x2{h01, h23};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) + off_hi + (size_t)(COUT / 8) * img_pix * 16) = u32x2{x01, x23};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + off) = u32x2{l01, l23};
-      } else {
-        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) + off) = u32x2{h01, h23};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out2) + off) = u32x2{l01, l23};
+        xx[q][0] = bf16k::pack_bf16(v[0] - __uint_as_float(hh[q][0] << 16), v[1] - __uint_as_float(hh[q][0] & 0xffff0000u));
+        xx[q][1] = bf16k::pack_bf16(v[2] - __uint_as_float(hh[q][1] << 16), v[3] - __uint_as_float(hh[q][1] & 0xffff0000u));
       }
+    }
+    // (a, b) -> lanes 0-31: (a, a of lane + 32); lanes 32-63: (b of lane - 32, b): with a = quad g0's register and b = quad
+    // g0 + 1's, every lane ends up with channels 0-3 | 4-7 of ITS block (g0 + hsel)
+    auto piece = [&](const unsigned (&r)[2][2]) __attribute__((always_inline)) -> u32x4 {
+      const auto s01 = __builtin_amdgcn_permlane32_swap(r[0][0], r[1][0], false, false);
+      const auto s23 = __builtin_amdgcn_permlane32_swap(r[0][1], r[1][1], false, false);
+      return u32x4{s01[0], s23[0], s01[1], s23[1]};
+    };
+    const u32x4 ph = piece(hh), pl = piece(ll);
+    u32x4 px = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (X3) px = piece(xx);
+    if constexpr ((FIRST16_ABL & 1) != 0) {
+      asm volatile("" ::"v"(ph), "v"(pl), "v"(px));
+    } else {
+      const int cb = (slab * NT + wn * (32 * MB) + mb * 32) / 8 + g0 + hsel;      // this lane's 8-channel block
+      const bool have = valid && y < p.h && x < p.w;
+      // 32-bit arithmetic: every offset inside one image's plane is below 2^31 (launcher); a select, not a branch
+      const unsigned off = have ? ((unsigned)cb * (unsigned)img_pix + (unsigned)(y * p.w + x)) * 16u : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(ph, so.out, (int)off, 0, 0);
+      if constexpr (X3)      // hx: plane 0 = hi, plane 1 = xl = bf16(x - hi), one plane further in the same image
+        __builtin_amdgcn_raw_buffer_store_b128(px, so.out, (int)off, (int)((size_t)(COUT / 8) * img_pix * 16), 0);
+      __builtin_amdgcn_raw_buffer_store_b128(pl, so.out2, (int)off, 0, 0);
     }
   };
 
   // Rotated loop: iteration `it` first takes over tile it-1's accumulators (`held`), then computes tile `it` while
   // held's sixteen pieces leave two per tap; one extra iteration writes the last tile out at once.
+  // What bounds it (timing-only variant builds, tools/ab_first16.sh, profiles/r05_first16_ab.txt; DSen2_20 batch 512): gather +
+  // LDS + barrier skeleton alone 28 us (eight tiles per workgroup, each waiting one HBM latency for its gather), + MFMAs 7 us
+  // (bf16x3: 28), + stores 24 us (30) = the 59 us (90) measured — the three add up instead of overlapping, because a tile's
+  // gather queues behind the previous tile's sixteen stores in the CU's in-order vector-memory path.  A gather TWO tiles ahead
+  // would hide it, but needs two register sets in flight across the loop's back edge, and hipcc shuffles them with moves that
+  // wait for the loads (tried: the waits come back as vmcnt(16) at the top of the second copy); staging through LDS by DMA
+  // does not fit next to the bf16x3 operand planes.  Left at one tile ahead: the layer is 3.6 % (2.3 %) of its step.
   f32x16 acc[MB][PB], held[MB][PB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -223,13 +266,14 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
   for (int it = 0; it <= my_items; ++it) {
     const Tile tprev = tile_of(it > 0 ? lid + (it - 1) * G : lid);
     const bool vprev = it > 0;
+    const StoreRsrc sprev = store_rsrc(tprev);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) held[mb][pb] = acc[mb][pb];
     if (it == my_items) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) store_piece(j, held, tprev, vprev);
+      for (int tp = 0; tp < 8; ++tp) store_pair(tp, held, tprev, sprev, vprev);
       break;
     }
     const int item = lid + it * G;
@@ -237,7 +281,8 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
     char* const ib_next = in_s + ((it + 1) & 1) * (PL * IN_PLANE_BYTES);
     // the next tile's input: its loads fly under this tile's MFMAs and stores (past the last item: this tile again, never read)
     float nv[ROUNDS];
-    gather(tile_of(it + 1 < my_items ? item + G : item), nv);
+    if constexpr ((FIRST16_ABL & 4) == 0) gather(tile_of(it + 1 < my_items ? item + G : item), nv);
+    else for (int r = 0; r < ROUNDS; ++r) nv[r] = 1.f;
 
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -261,7 +306,7 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
       }
       // precision 1: x * w.  precision 2: xh*wh + xh*wl + xl*wh (operand planes 0 = hi, 1 = lo)
 #pragma unroll
-      for (int term = 0; term < (X3 ? 3 : 1); ++term) {
+      for (int term = 0; term < ((FIRST16_ABL & 2) ? 0 : X3 ? 3 : 1); ++term) {
         const int qa = term == 1 ? 1 : 0, qb = term == 2 ? 1 : 0;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
@@ -272,13 +317,13 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
       __builtin_amdgcn_sched_barrier(0);
       // two pieces of the previous tile, issued behind this tap's MFMAs
       if (tap < 8) {
-        store_piece(2 * tap, held, tprev, vprev);
-        store_piece(2 * tap + 1, held, tprev, vprev);
+        store_pair(tap, held, tprev, sprev, vprev);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
 
-    // the next tile's halo into the other buffer (every wave read it for the last time one barrier ago)
+    // the next tile's halo into the other buffer (every wave read it for the last time one barrier ago); the loop body has no
+    // divergent branch, so hipcc's waits here are exact: vmcnt(16 stores + the younger loads), not a drain of the stores
     scatter(ib_next, nv);
     __syncthreads();
   }
