@@ -24,7 +24,7 @@
 // same three-MFMA form as the residual blocks (conv3x3_body16w.hip, X3); the xl*wl term is 2^-18 of the product.
 // The output is the residual stream in the form the body kernels read: precision 1 the blocked (hi, lo) planes, precision
 // 2 hx = (hi | xl) planes + lo16 (conv3x3_first.hip's kEpiReluSplit / kEpiReluSplit3 epilogues, same code).
-// Parity: tests/test_gpu_first16.py (against the float64 oracle on the operands the kernel multiplies; ragged shapes;
+// Parity: tests/test_gpu_first16.py (against a float64 restatement on the operands the kernel multiplies; ragged shapes;
 // DSen2_60's 12 channels) and the whole-network gates of tests/test_gpu_bf16.py / test_gpu_bf16x3.py.
 #include <string.h>
 
