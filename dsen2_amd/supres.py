@@ -133,9 +133,16 @@ def _run(dsets, scales, patch, border, deep, run_60):
     # (dist.ChunkedGather) and rank 0 recomposes + downloads what has arrived under the remaining work, instead of one
     # gather at the very end followed by recomposition and 51 ms of D2H on rank 0 alone.  Off by default until
     # an N > 1 box has measured RCCL's kernels next to two CU-filling persistent ones; the result is the same image.
-    cg, next_chunk = None, 0
+    cg, next_chunk, cg_img, cg_ready = None, 0, None, None
     if send is not None and _chunked_gather_wanted():
         cg = _dist.ChunkedGather(send, used, _gather_chunks())
+        if rank == 0:
+            # the image rank 0 recomposes into, allocated NOW and fenced by an event: its tail stream may then start on the
+            # first piece while the shard is still computing — waiting for the compute stream later (wait_stream) would wait
+            # for the whole shard and put recomposition + download back after it
+            cg_img = torch.empty((int(size[0]), int(size[1]), cout), dtype=torch.float32, device=dev)
+            cg_ready = torch.cuda.Event()
+            cg_ready.record(torch.cuda.current_stream(dev))
     bands = None                     # one rank, large image: the bands of rows already recomposed (below)
     if count > 0:
         # upload only the rows this rank's patches read (1/world of the tile), origins shifted into the slab
@@ -212,7 +219,7 @@ def _run(dsets, scales, patch, border, deep, run_60):
     # buffer the result is downloaded into now, under that work (0.18 s for a 10980^2 x 6 image; the download itself
     # then runs at 57 GB/s instead of 11 GB/s from pageable memory: 0.05 s instead of 0.26 s).
     if cg is not None:
-        return _finish_chunked(cg, next_chunk, rank, dev, size, cout, inner)
+        return _finish_chunked(cg, next_chunk, rank, dev, size, cout, inner, cg_img, cg_ready)
     host = _host_output((int(size[0]), int(size[1]), cout)) if rank == 0 else None
     if world == 1:
         print((cout, size[0], size[1]))                                # patches.py:392
@@ -242,7 +249,7 @@ def _gather_chunks():
     return max(1, int(os.environ.get('DSEN2_GATHER_CHUNKS', '8')))
 
 
-def _finish_chunked(cg, next_chunk, rank, dev, size, cout, inner):
+def _finish_chunked(cg, next_chunk, rank, dev, size, cout, inner, img, ready):
     """The tail of a sharded run with the chunked gather.  Every rank: the pieces it has not issued yet (a rank whose shard
     is short or empty still takes part in every gather).  Rank 0: on a stream of its own — so that its compute stream never
     waits for RCCL — piece by piece: wait for the gather, recompose the image rows whose patches have all arrived (the crops
@@ -257,13 +264,12 @@ def _finish_chunked(cg, next_chunk, rank, dev, size, cout, inner):
         return None
     print((cout, size[0], size[1]))                                    # patches.py:392
     H, W = int(size[0]), int(size[1])
-    host = _host_output((H, W, cout))
-    img = torch.empty((H, W, cout), dtype=torch.float32, device=dev)
+    host = _host_output((H, W, cout))          # page-locked, allocated under the work already enqueued
     x_tiles, y_tiles = int(np.ceil(W / float(inner))), int(np.ceil(H / float(inner)))
     slot = np.arange(x_tiles * y_tiles) % cg.per                       # a patch's slot in its rank's shard
     done_rows = np.zeros(y_tiles, bool)
     tail = torch.cuda.Stream(dev)
-    tail.wait_stream(torch.cuda.current_stream(dev))                   # `img` / `recv` were allocated on the compute stream
+    tail.wait_event(ready)                     # `img` / `recv` exist as far as the compute stream is concerned (NOT: the shard is done)
     with torch.cuda.stream(tail):
         for c in range(cg.n_chunks):
             cg.complete(c)
