@@ -249,13 +249,11 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
 
   // Rotated loop: iteration `it` first takes over tile it-1's accumulators (`held`), then computes tile `it` while
   // held's sixteen pieces leave two per tap; one extra iteration writes the last tile out at once.
-  // What bounds it (timing-only variant builds, tools/ab_first16.sh, profiles/r05_first16_ab.txt; DSen2_20 batch 512): gather +
-  // LDS + barrier skeleton alone 28 us (eight tiles per workgroup, each waiting one HBM latency for its gather), + MFMAs 7 us
-  // (bf16x3: 28), + stores 24 us (30) = the 59 us (90) measured — the three add up instead of overlapping, because a tile's
-  // gather queues behind the previous tile's sixteen stores in the CU's in-order vector-memory path.  A gather TWO tiles ahead
-  // would hide it, but needs two register sets in flight across the loop's back edge, and hipcc shuffles them with moves that
-  // wait for the loads (tried: the waits come back as vmcnt(16) at the top of the second copy); staging through LDS by DMA
-  // does not fit next to the bf16x3 operand planes.  Left at one tile ahead: the layer is 3.6 % (2.3 %) of its step.
+  // What bounds it (timing-only variant builds, tools/ab_first16.sh, profiles/r05_first16_ab.txt; DSen2_20, batch 512): the
+  // STORES.  Without stores the kernel takes 36 us (bf16x3: 64), without MFMAs 54 us (71), complete 58-59 us (90): 268 MB
+  // (402 MB) of plane writes at 4.6 TB/s (4.5), against 47 us measured for the same bytes as fp32 stores alone in round 3.  A
+  // gather two tiles ahead (two register sets alternating over a twice-unrolled loop: exact counted waits, no register moves)
+  // was built and measured: 58.0 us against 58.7 — the gather's latency is not what is exposed; left at one tile ahead.
   f32x16 acc[MB][PB], held[MB][PB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)

@@ -63,3 +63,32 @@ def test_full_tile_chunked_gather_over_rccl_equals_the_single_rank_image():
     r = _json_line(_launch(2, os.path.join(ROOT, 'tools', 'bench_full_tile.py'), '--size', '10980', '--skip60', '--backend',
                            'nccl', '--check', cwd=ROOT, env=env))
     assert r['n_gpus'] == 2 and r['matches_single_rank'] is True and r.get('chunked_gather') is True
+
+
+def test_cli_two_ranks_over_rccl_writes_the_single_rank_file(tmp_path):
+    """The drop-in command line (the stand-in for testing/s2_tiles_supres.py:332-342,371-420) with one process per GPU over
+    RCCL: rank 0 alone prints and writes, the same bytes per band as the single-process run; with the chunked gather too."""
+    sys.path.insert(0, ROOT)
+    from dsen2_amd import weights
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'tile_T33UUB_crop.npz'))
+    inp = str(tmp_path / 'tile.npz')
+    np.savez(inp, data10=g['d10'], data20=g['d20'], data60=g['d60'])
+    mdl = tmp_path / 'models'
+    mdl.mkdir()
+    np.save(str(mdl / 's2_032_lr_1e-04.npy'), weights.random_he_uniform(10, 6, 6, 128, seed=11))
+    np.save(str(mdl / 's2_030_lr_1e-05.npy'), weights.random_he_uniform(12, 2, 6, 128, seed=12))
+    common = ['--run_60', '--copy_original_bands', '--models', str(mdl)]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    single = subprocess.run([sys.executable, '-m', 'dsen2_amd.cli', inp, str(tmp_path / 'one.npz')] + common,
+                            capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert single.returncode == 0, single.stderr[-2000:]
+    one = np.load(str(tmp_path / 'one.npz'), allow_pickle=True)['bands'].item()
+    for name, extra_env in (('two', {}), ('two_chunked', {'DSEN2_CHUNKED_GATHER': '1'})):
+        out = str(tmp_path / (name + '.npz'))
+        p = _launch(2, '-m', 'dsen2_amd.cli', inp, out, *common, cwd=str(tmp_path), env=dict(env, **extra_env))
+        assert p.returncode == 0, p.stderr[-3000:]
+        assert p.stdout.count('Super-resolving the 20m data into 10m bands') == 1          # one rank talked
+        two = np.load(out, allow_pickle=True)['bands'].item()
+        assert list(one) == list(two)
+        for k in one:
+            assert np.array_equal(one[k], two[k]), (name, k)
