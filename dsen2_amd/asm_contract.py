@@ -206,6 +206,40 @@ def check_out_mfma_listing(text, src='conv3x3_out_mfma.hip'):
     return True
 
 
+def check_first16_listing(text, src='conv3x3_first16.hip'):
+    """conv3x3_first16.hip relies on hipcc's own wait counts, which are only exact while the tile loop's body has no divergent
+    branch, and on 128-bit buffer stores whose soffset is the IMMEDIATE 0 (with a register soffset gfx950 reads the store data
+    late and hipcc does not pad the hazard: experiments/README.md)."""
+    def need(cond, msg, ctx=()):
+        if not cond:
+            raise AsmContractError('%s: %s %s' % (src, msg, list(ctx)))
+
+    kernels = {k: v for k, v in _kernels(text).items() if 'conv3x3_first16_kernel' in k}
+    need(len(kernels) == 8, 'expected 8 instantiations of the kernel, found %d' % len(kernels))
+    for name, body in kernels.items():
+        need(not any('scratch_' in ln for ln in body), 'kernel %s spills registers' % name)
+        need(not any(ln.startswith(('s_swappc', 's_call')) for ln in body), 'kernel %s calls a function' % name)
+        stores = [ln for ln in body if ln.startswith('buffer_store_dwordx4')]
+        need(stores, 'kernel %s has no 128-bit buffer store' % name)
+        bad = [ln for ln in stores if not re.search(r'\], 0 offen', ln)]
+        need(not bad, 'kernel %s: 128-bit buffer store with a register soffset (late data read, unpadded hazard)' % name, bad[:2])
+        need(not any(ln.startswith('global_store') for ln in body), 'kernel %s stores outside its buffer descriptors' % name)
+        # the halo scatter (ds_write_b16) inside the tile loop may only wait for its own loads: with the 16 (bf16x3: 24) stores of
+        # the previous tile issued after them, every counted wait in front of a scatter write must leave at least that many
+        # operations in flight.  (The prologue's scatter, before the first MFMA, drains: nothing else is in flight there.)
+        mf = [i for i, ln in enumerate(body) if ln.startswith('v_mfma')]
+        need(mf, 'kernel %s has no MFMA' % name)
+        x3 = 'ELb1EEE' in name                      # template argument X3 = true
+        floor = 24 if x3 else 16
+        loop = body[mf[0]:]
+        scat = [i for i, ln in enumerate(loop) if ln.startswith('ds_write_b16')]
+        need(scat, 'kernel %s: no halo scatter after the first MFMA' % name)
+        waits = [ln for ln in loop[:scat[-1]] if ln.startswith('s_waitcnt') and 'vmcnt' in ln]
+        low = [ln for ln in waits if int(re.search(r'vmcnt\((\d+)\)', ln).group(1)) < floor]
+        need(not low, 'kernel %s: a wait inside the tile loop drains the deferred stores (divergent branch in the loop body?)' % name, low[:4])
+    return True
+
+
 # The kernels whose measured HBM traffic bench.py quotes from profiles/body_conv_traffic.json (PMC counters cannot be read
 # in-process): config -> (source file, regular expression on the mangled name).  Their ISA hash is written next to the
 # library at build time (kernel_isa.json) and next to the traffic figure when tools/update_traffic_json.py records it, so
@@ -248,7 +282,7 @@ def check_sources(hipcc, flags, verbose=False, isa_json=None):
     compiled (and writes it to `isa_json` when given: dsen2_amd.build does, next to the library)."""
     listings = {}
     with tempfile.TemporaryDirectory(prefix='dsen2_asm_') as tmp:
-        for src in DMA_SOURCES + ['conv3x3_out_mfma.hip']:
+        for src in DMA_SOURCES + ['conv3x3_out_mfma.hip', 'conv3x3_first16.hip']:
             out = os.path.join(tmp, src + '.s')
             cmd = [hipcc] + [f for f in flags if f not in ('-fPIC',)] + ['-S', '--cuda-device-only', os.path.join(CSRC, src), '-o', out]
             if verbose:
@@ -258,6 +292,8 @@ def check_sources(hipcc, flags, verbose=False, isa_json=None):
                 listings[src] = f.read()
             if src in DMA_SOURCES:
                 check_listing(listings[src], src)
+            elif src == 'conv3x3_first16.hip':
+                check_first16_listing(listings[src], src)
             else:
                 check_out_mfma_listing(listings[src], src)
     hashes = traffic_kernel_hashes(listings)

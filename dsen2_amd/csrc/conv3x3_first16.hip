@@ -241,8 +241,12 @@ __global__ __launch_bounds__(first16::THREADS, 2) void conv3x3_first16_kernel(co
       // 32-bit arithmetic: every offset inside one image's plane is below 2^31 (launcher); a select, not a branch
       const unsigned off = have ? ((unsigned)cb * (unsigned)img_pix + (unsigned)(y * p.w + x)) * 16u : 0x80000000u;
       __builtin_amdgcn_raw_buffer_store_b128(ph, so.out, (int)off, 0, 0);
-      if constexpr (X3)      // hx: plane 0 = hi, plane 1 = xl = bf16(x - hi), one plane further in the same image
-        __builtin_amdgcn_raw_buffer_store_b128(px, so.out, (int)off, (int)((size_t)(COUT / 8) * img_pix * 16), 0);
+      // hx: plane 0 = hi, plane 1 = xl = bf16(x - hi), one plane further in the same image.  The plane offset goes into the
+      // VECTOR offset (one add), soffset stays the immediate 0: a 128-bit buffer store with a REGISTER soffset reads its data
+      // late on gfx950 and hipcc does not pad that hazard (experiments/README.md, round 1).  An out-of-range lane stays out
+      // of range: 2^31 + a plane (< 2^30) does not wrap.
+      if constexpr (X3)
+        __builtin_amdgcn_raw_buffer_store_b128(px, so.out, (int)(off + (unsigned)((size_t)(COUT / 8) * img_pix * 16)), 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(pl, so.out2, (int)off, 0, 0);
     }
   };

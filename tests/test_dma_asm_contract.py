@@ -115,3 +115,35 @@ def test_output_kernel_checker():
         asm_contract.check_out_mfma_listing(OUT_GOOD.replace('s_endpgm', 'scratch_load_dword v0, off, off\n\ts_endpgm', 1))
     with pytest.raises(asm_contract.AsmContractError):       # an instantiation missing
         asm_contract.check_out_mfma_listing(OUT_GOOD.replace('ILi256ELi3E', 'ILi256ELi1E'))
+
+
+FIRST16_GOOD = '\n'.join(
+    '''_ZN5dsen222conv3x3_first16_kernelILi%dELi%dELb%dEEEvNS_10ConvParamsENS_11FirstInputsEi:
+	buffer_load_dword v1, v2, s[20:23], 0 offen
+	s_waitcnt vmcnt(0)
+	ds_write_b16 v3, v1 offset:36864
+	s_barrier
+	buffer_load_dword v1, v2, s[20:23], 0 offen
+	v_mfma_f32_32x32x16_bf16 v[96:111], v[64:67], v[68:71], v[96:111]
+	buffer_store_dwordx4 v[68:71], v78, s[28:31], 0 offen
+	s_waitcnt vmcnt(%d)
+	ds_write_b16 v3, v1 offset:52416
+	s_barrier
+	s_endpgm
+''' % (c, f, x, 24 if x else 16) for c in (10, 12) for f in (128, 256) for x in (0, 1))
+
+
+def test_first16_contract_catches_what_it_is_for():
+    """conv3x3_first16.hip: exact counted waits inside the tile loop (no drain of the deferred stores), 128-bit buffer stores
+    only with the immediate soffset 0 (gfx950's late data read with a register soffset: experiments/README.md), no spills."""
+    asm_contract.check_first16_listing(FIRST16_GOOD)
+    with pytest.raises(asm_contract.AsmContractError):            # a register soffset on a 128-bit store
+        asm_contract.check_first16_listing(FIRST16_GOOD.replace('s[28:31], 0 offen', 's[28:31], s33 offen', 1))
+    with pytest.raises(asm_contract.AsmContractError):            # a wait in the loop that drains the stores
+        asm_contract.check_first16_listing(FIRST16_GOOD.replace('vmcnt(16)', 'vmcnt(6)', 1))
+    with pytest.raises(asm_contract.AsmContractError):            # a spill
+        asm_contract.check_first16_listing(FIRST16_GOOD.replace('s_endpgm', 'scratch_load_dword v0, off, off\n\ts_endpgm', 1))
+    with pytest.raises(asm_contract.AsmContractError):            # a store that bypasses the per-image descriptors
+        asm_contract.check_first16_listing(FIRST16_GOOD.replace('s_endpgm', 'global_store_dwordx4 v[0:1], v[2:5], off\n\ts_endpgm', 1))
+    with pytest.raises(asm_contract.AsmContractError):            # an instantiation missing
+        asm_contract.check_first16_listing(FIRST16_GOOD.replace('ILi12ELi256ELb1E', 'ILi12ELi256ELb0E'))

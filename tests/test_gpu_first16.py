@@ -6,6 +6,8 @@ the SAME rounded operands only the fp32 summation differs: the check is tight.  
 per fp32 product, error ~2^-17 of each: checked against the float64 oracle on the fp32 operands with the body kernels' gate.
 Both: the planes written are exactly the split of one fp32 result (what the residual blocks read), zero padding at the image
 edges, ragged sizes, DSen2_60's 12 channels, batches larger than the grid."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -108,3 +110,31 @@ def test_models_with_other_band_groups_still_run_through_the_generic_first_layer
         y = m.predict(xs)
         ref = c_oracle.forward(xs, flat, 1, 128)
         assert do.rmse(y, ref) < gate
+
+
+@pytest.mark.parametrize('precision,feat,bands', [(1, 128, (4, 6)), (2, 128, (4, 6)), (2, 256, (4, 6, 2))])
+def test_first_convolution_planes_over_many_launches_on_fresh_data(precision, feat, bands):
+    """Hazard screen (the kernel's 128-bit buffer stores leave under the next tile's MFMAs and v_permlane32_swap feeds them;
+    gfx950 reads store data late): 40 launches on fresh random inputs at several items per workgroup, every plane compared with a
+    SECOND launch on the same inputs bit for bit, and the fp32 value the planes hold with the float64 restatement."""
+    from dsen2_amd.DSen2Net import conv3x3_first_planes, join_f32
+    reps = 40 * int(os.environ.get('DSEN2_STRESS_REPS', '1'))
+    rng = np.random.default_rng(precision * 1000 + feat)
+    cin = sum(bands)
+    k = (rng.uniform(-1, 1, (3, 3, cin, feat)) * np.sqrt(6.0 / (9 * cin))).astype(np.float32)
+    b = (rng.standard_normal(feat) * 0.1).astype(np.float32)
+    bad = 0
+    for i in range(reps):
+        n, h, w = [(64, 32, 32), (300, 16, 16), (7, 48, 40), (513, 32, 32)][i % 4]
+        dev = [torch.rand((n, c, h, w), device='cuda') * 5 for c in bands]
+        o1, l1 = conv3x3_first_planes(dev, k, b, precision=precision)
+        o2, l2 = conv3x3_first_planes(dev, k, b, precision=precision)
+        bad += int(not (torch.equal(o1, o2) and torch.equal(l1, l2)))
+        if i % 10 == 0:
+            xs = np.concatenate([d[:2].cpu().numpy() for d in dev], axis=1)
+            kk = bf16_round(k) if precision == 1 else k
+            ref = c_oracle.conv3x3(bf16_round(xs) if precision == 1 else xs, kk, b, relu=True)
+            hi = o1[:2] if precision == 1 else o1[:2, 0].contiguous()
+            y = join_f32(hi.contiguous(), l1[:2].contiguous()).cpu().numpy().transpose(0, 3, 1, 2)
+            assert do.rmse(y, ref) < 5e-6 * max(float(np.sqrt(np.mean(ref ** 2))), 1.0)
+    assert bad == 0
