@@ -62,7 +62,11 @@ def _fletcher32(data):
     n = len(data) // 2
     w = np.frombuffer(data, '>u2', n).astype(np.uint64)
     s1 = int(w.sum())
-    s2 = int((w * np.arange(n, 0, -1, dtype=np.uint64)).sum()) if n < (1 << 24) else sum(int(x) * (n - i) for i, x in enumerate(w))
+    # s2 = sum of the running sums = sum_i (n - i) * w_i; in blocks, so that no partial sum leaves 64 bits whatever the chunk's size
+    s2, block = 0, 1 << 15
+    for a in range(0, n, block):
+        b = min(n, a + block)
+        s2 += int((w[a:b] * np.arange(n - a, n - b, -1, dtype=np.uint64)).sum())
     if len(data) & 1:
         s1 += data[-1] << 8
         s2 += s1
