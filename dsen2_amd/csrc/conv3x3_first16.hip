@@ -23,7 +23,7 @@
 // precision 2: x = xh + xl, w = wh + wl (weights split at pack time), a product = xh*wh + xh*wl + xl*wh in fp32 — the
 // same three-MFMA form as the residual blocks (conv3x3_body16w.hip, X3); the xl*wl term is 2^-18 of the product.
 // The output is the residual stream in the form the body kernels read: precision 1 the blocked (hi, lo) planes, precision
-// 2 hx = (hi | xl) planes + lo16 (conv3x3_first.hip's kEpiReluSplit / kEpiReluSplit3 epilogues, same code).
+// 2 hx = (hi | xl) planes + lo16 (what launch_split_f32 / launch_split3_f32 make of an fp32 tensor).
 // Parity: tests/test_gpu_first16.py (against a float64 restatement on the operands the kernel multiplies; ragged shapes;
 // DSen2_60's 12 channels) and the whole-network gates of tests/test_gpu_bf16.py / test_gpu_bf16x3.py.
 #include <string.h>

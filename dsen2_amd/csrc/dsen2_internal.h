@@ -29,8 +29,8 @@ constexpr int kHaloPix = kHalo * kHalo;   // 324
 enum Epilogue : int {
   kEpiRelu = 0, kEpiResidual = 1, kEpiSkipNCHW = 2,
   kEpiResidualF32 = 3,   // bf16 body kernel only
-  kEpiReluSplit = 4,     // first convolution of a precision-1 model: relu(conv + b) written as blocked (hi, lo) planes (out, out2)
-  kEpiReluSplit3 = 5     // ... of a precision-2 model: out = the stream's operand tensor (two planes per image: hi | xl), out2 = lo16
+  kEpiReluSplit = 4      // generic first convolution of a precision-1 model (conv3x3_mfma.hip; band groups conv3x3_first16.hip does
+                         // not take): relu(conv + b) written as blocked (hi, lo) planes (out, out2)
 };
 
 struct ConvParams {
