@@ -122,9 +122,11 @@ def init_from_env(backend='nccl'):
     n_dev = torch.cuda.device_count()            # counting devices does not initialise HIP
     if n_dev == 0:
         raise RuntimeError('dsen2_amd needs a ROCm GPU (gfx950); there is no CPU fallback')
-    if backend == 'nccl' and local_rank >= n_dev:
+    pinned = n_dev == 1 and any(os.environ.get(k) for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+    if backend == 'nccl' and local_rank >= n_dev and not pinned:
         raise RuntimeError('LOCAL_RANK %d but %d GPU(s) visible: RCCL needs one GPU per rank '
                            '(backend gloo rehearses with shared devices)' % (local_rank, n_dev))
+    # (`pinned`: a launcher that gives every rank its own *_VISIBLE_DEVICES shows each process ONE device, number 0)
     dev = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(dev)
     if world > 1 and not td.is_initialized():
