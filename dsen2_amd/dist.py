@@ -318,3 +318,74 @@ def broadcast_weights(flat, count, device=None, src=0):
         t = torch.empty(count, dtype=torch.float32, device=dev)
     td.broadcast(t, src=src)
     return t.cpu().numpy()
+
+
+def _preflight(argv=None):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m dsen2_amd.dist [--backend gloo]
+
+    Pre-flight of the N-GPU path WITHOUT the network: first contact (guarded: fails fast, says where), then the two
+    collectives of the product with their real sizes — C1, one broadcast of the DSen2 weight vector (7.16 MB), and C2, the
+    bench's per-step gather of 512 x 6 x 32 x 32 float32 outputs per rank (12.6 MB) — timed over 20 repetitions, plus one
+    chunked gather of a full-tile shard's size.  Rank 0 prints one JSON line: what a node delivers per xGMI link before any
+    kernel of ours runs (DESIGN §6 prices the gather at 48 GB/s per link)."""
+    import argparse
+    import json
+    ap = argparse.ArgumentParser(prog='python -m dsen2_amd.dist')
+    ap.add_argument('--backend', default='nccl', choices=list(BACKENDS))
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--shard-patches', type=int, default=1226, help='patches of 6 x 112 x 112 float32 per rank for the chunked gather (1226 = a 10980^2 tile over 8 ranks)')
+    args = ap.parse_args(argv)
+    rank, world, dev = init_from_env(args.backend)
+    cdev = dev if args.backend == 'nccl' else torch.device('cpu')
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    out = {'world': world, 'backend': 'rccl' if args.backend == 'nccl' else 'gloo', 'first_contact': first_contact()}
+    if world > 1:
+        with guarded_step('broadcast 7.16 MB (C1)'):
+            w = torch.zeros(1790000, dtype=torch.float32, device=cdev)
+            td.broadcast(w, src=0)
+            sync()
+        with guarded_step('gather 12.6 MB per rank (C2), %d repetitions' % args.reps):
+            send = torch.full((512, 6, 32, 32), float(rank), dtype=torch.float32, device=cdev)
+            recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+            td.gather(send, recv, dst=0)            # warm: RCCL sets its channels up here
+            sync()
+            td.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                td.gather(send, recv, dst=0)
+            sync()
+            td.barrier()
+            dt = (time.perf_counter() - t0) / args.reps
+            ok = rank != 0 or all(float(recv[r][0, 0, 0, 0]) == float(r) for r in range(world))
+            out['gather_12p6MB_ms'] = round(dt * 1e3, 3)
+            out['gather_GBps_per_peer_link'] = round(send.numel() * 4 / dt / 1e9, 2)       # every peer sends its 12.6 MB in that time
+            out['gather_payload_ok'] = bool(ok)
+        with guarded_step('chunked gather of a full-tile shard'):
+            per = args.shard_patches
+            shard = torch.full((per, 6, 112, 112), float(rank), dtype=torch.float32, device=dev)
+            sync()
+            td.barrier()
+            t0 = time.perf_counter()
+            cg = ChunkedGather(shard, per * world, 8)
+            for c in range(cg.n_chunks):
+                cg.issue(c)
+            for c in range(cg.n_chunks):
+                cg.complete(c)
+            sync()
+            td.barrier()
+            dt = time.perf_counter() - t0
+            out['chunked_gather_s'] = round(dt, 4)
+            out['chunked_gather_GBps_per_peer_link'] = round(shard.numel() * 4 / dt / 1e9, 2)
+            if rank == 0:
+                out['chunked_payload_ok'] = bool(all(float(cg.recv[r * per, 0, 0, 0]) == float(r) and float(cg.recv[r * per + per - 1, 5, 111, 111]) == float(r)
+                                                     for r in range(world)))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    finalize()
+
+
+if __name__ == '__main__':
+    _preflight()

@@ -243,3 +243,17 @@ def test_cli_two_ranks_gloo_writes_the_single_rank_file_from_rank_0_only(tmp_pat
     assert list(one) == list(two) and len(one) == 12
     for k in one:
         assert np.array_equal(one[k], two[k]), k
+
+
+def test_dist_preflight_two_ranks_gloo():
+    """python -m dsen2_amd.dist: first contact + the product's two collectives at their real sizes, without the network — what an
+    operator runs on a new node before the bench.  Two ranks over gloo on the one GPU: control flow and payload checks (the
+    rates it prints mean nothing here)."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', _free_port(), '-m', 'dsen2_amd.dist', '--backend', 'gloo', '--reps', '3', '--shard-patches', '37']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert r['world'] == 2 and r['first_contact']['ranks_in_collective'] == 2
+    assert r['gather_payload_ok'] is True and r['chunked_payload_ok'] is True and r['gather_12p6MB_ms'] > 0

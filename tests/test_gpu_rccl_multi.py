@@ -92,3 +92,12 @@ def test_cli_two_ranks_over_rccl_writes_the_single_rank_file(tmp_path):
         assert list(one) == list(two)
         for k in one:
             assert np.array_equal(one[k], two[k]), (name, k)
+
+
+def test_dist_preflight_two_ranks_over_rccl():
+    """python -m dsen2_amd.dist over RCCL: the first figures a node gives for the gather DESIGN §6 prices at 48 GB/s per link."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = _json_line(_launch(2, '-m', 'dsen2_amd.dist', cwd=ROOT, env=env))
+    print('pre-flight over RCCL:', r)
+    assert r['world'] == 2 and r['backend'] == 'rccl' and r['first_contact']['ranks_in_collective'] == 2
+    assert r['gather_payload_ok'] is True and r['chunked_payload_ok'] is True
