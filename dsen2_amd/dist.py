@@ -140,7 +140,13 @@ def connect(backend, rank, world, dev=None):
     timeout = datetime.timedelta(seconds=timeout_s())
     with guarded_step('init_process_group(%s)' % backend):
         if backend == 'nccl':
-            td.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, timeout=timeout)
+            # DSEN2_RCCL_HIGH_PRIORITY=1: RCCL's kernels on a high-priority stream — both body kernels fill every CU, so a
+            # gather in flight is dispatched at a launch boundary; with priority it is the first thing dispatched there.  Off by
+            # default: an A/B for the first N > 1 box (bench.py's gather_wait_ms_per_step / ms_per_step_no_gather show it).
+            opts = None
+            if os.environ.get('DSEN2_RCCL_HIGH_PRIORITY', '0') not in ('', '0'):
+                opts = td.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            td.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, timeout=timeout, pg_options=opts)
         else:
             td.init_process_group('gloo', rank=rank, world_size=world, timeout=timeout)
     # the first collective is where RCCL builds its rings / exchanges IPC handles: do it HERE, guarded, with a payload

@@ -211,6 +211,32 @@ def test_rccl_initialises_and_runs_the_bench_collectives_on_one_rank():
     assert p.returncode == 0 and 'rccl one rank ok' in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
 
 
+_RCCL_CONNECT_ONE_RANK = r'''
+import torch
+from dsen2_amd import dist
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.connect('nccl', 0, 1, dev)                      # the product's own entry: timeout, guarded steps, counting all-reduce
+assert dist.first_contact()['ranks_in_collective'] == 1
+t = torch.ones(4, device=dev)
+torch.distributed.all_reduce(t)
+torch.cuda.synchronize()
+dist.finalize()
+print('connect ok')
+'''
+
+
+@pytest.mark.parametrize('high_priority', ['0', '1'])
+def test_dist_connect_over_rccl_on_one_rank(high_priority):
+    """dist.connect over backend "nccl" as the product calls it (group timeout, guarded steps, the counting all-reduce), with
+    and without DSEN2_RCCL_HIGH_PRIORITY — one rank: the most a one-GPU box can show."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0', DSEN2_RCCL_HIGH_PRIORITY=high_priority,
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    p = subprocess.run([sys.executable, '-c', _RCCL_CONNECT_ONE_RANK], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0 and 'connect ok' in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+
+
 def test_cli_two_ranks_gloo_writes_the_single_rank_file_from_rank_0_only(tmp_path):
     """The drop-in CLI under torch.distributed.run (the stand-in for testing/s2_tiles_supres.py:332-342,371-420 on N
     GPUs): `python -m torch.distributed.run ... -m dsen2_amd.cli tile.npz out.npz` with 2 ranks (gloo rehearsal, both on
