@@ -8,7 +8,8 @@
 // the rest of the step no longer uses.  With v_mfma_f32_32x32x16_bf16 a tap is ONE instruction per 32 x 32 output block
 // (the 10 / 12 channels in a 16-slot K, the unused slots zero on both sides): 9 (x 3) MFMAs per block and tile instead of
 // 45, each at 16 x the fp32 rate — the layer becomes what it should be, a streaming WRITE of the residual stream's planes
-// (268 MB at the bench batch; precision 2: 402 MB), with the gather of the 21 MB of inputs and the MFMAs underneath.
+// (268 MB at the bench batch; precision 2: 402 MB), with the gather of the 21 MB of inputs and the MFMAs underneath:
+// 139.5 -> 59 us (precision 2: 161 -> 90 us), store-bound at 4.6 TB/s (profiles/r05_first16_ab.txt).
 //
 // Structure = conv3x3_first.hip's, operand format aside:
 //   * persistent, one workgroup of 8 waves per CU walks tiles lid, lid + G, ... and keeps ONE 128-channel output slab:
@@ -17,8 +18,9 @@
 //     Concatenate is an address computation) while the current tile computes, then converted to bf16 and written into
 //     the other half of a double buffer as [halo pixel][16 channel slots] with a 48-byte pixel pitch (conflict-free
 //     ds_read_b128 over 16 pixels); precision 2 writes two planes, xh = bf16(x) and xl = bf16(x - xh);
-//   * the epilogue is DEFERRED: a finished tile's accumulators are written out two 16-byte pieces per tap inside the next
-//     tile's tap loop.
+//   * the epilogue is DEFERRED: a finished tile's accumulators are written out inside the next tile's tap loop, two 16-byte
+//     pieces per tap — as ONE 16-byte buffer store per lane and plane (v_permlane32_swap pairs the half-waves' quads), issued by
+//     every lane through per-image descriptors (out-of-range offsets instead of branches: the loop body is straight-line code).
 // Arithmetic.  precision 1: out = relu(sum_k bf16(x_k) * bf16(w_k) + b), every product exact in fp32, fp32 accumulate.
 // precision 2: x = xh + xl, w = wh + wl (weights split at pack time), a product = xh*wh + xh*wl + xl*wh in fp32 — the
 // same three-MFMA form as the residual blocks (conv3x3_body16w.hip, X3); the xl*wl term is 2^-18 of the product.
