@@ -55,7 +55,8 @@ int dsen2_device_count(void);
  *   feature_size must be a multiple of 128 (reference uses 128 and 256, testing/supres.py:56,59).
  *   precision: 0 = fp32 everywhere (exact-f32 MFMA); 1 = bf16 operands for the residual-block convolutions
  *   (v_mfma_f32_16x16x32_bf16), fp32 accumulation, an exact fp32 residual stream (kept as two 16-bit planes, see
- *   dsen2_split_f32), fp32 first and last convolution; 2 = "bf16x3": the residual-block convolutions on the bf16 matrix
+ *   dsen2_split_f32), the FIRST convolution in the same arithmetic (bf16 operands, fp32 accumulate: dsen2_conv3x3_first_planes;
+ *   band groups other than 4 + 6 (+ 2): fp32), fp32 last convolution; 2 = "bf16x3": the first and the residual-block convolutions on the bf16 matrix
  *   cores with every fp32 operand split into two bf16 numbers (x = hi + lo, 16 significant bits) and a product taken as
  *   hi*hi + hi*lo + lo*hi — three MFMAs at 16 x the fp32 MFMA rate, fp32 accumulation, the same exact fp32 residual
  *   stream; whole-network error ~1e-5 in the normalised domain (fp32: 3e-7, precision 1: 4e-3), inside the 1e-4 gate.
